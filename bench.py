@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the RAJNI token-pruning forward, ViT-B/16 @224, bf16,
+README 4-stage schedule, batch 256 per GPU (BASELINE.json configs[1]; configs[2] when --gpus 8).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward of one 256-image synthetic batch per GPU, images already resident in HBM
+(the reference's metric, rajni/eval.py:51-59, times exactly model(images) between two syncs).
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     - dominant kernel (the packed-token MFMA GEMM), timed live with HIP events on the
+                 launch stream inside the timed region (rajni_profile_* hooks of the C ABI);
+  cpu_baseline - the numpy oracle (oracle/rajni_oracle.py, a port of the reference algorithm) timed
+                 on this box's host cores on a bounded sample of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rajni-vit_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+README_SCHEDULE = {3: {"keep_ratio": 0.88, "update": True}, 4: {"keep_ratio": 0.88, "update": True},
+                   7: {"keep_ratio": 0.80, "update": True}, 8: {"keep_ratio": 0.72, "update": True}}
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_image(cfg, schedule):
+    from rajni_amd.wrapper.model import plan_token_counts
+    from rajni_amd.ops import keep_count
+    C, Hd = cfg.embed_dim, cfg.hidden_dim
+    counts = plan_token_counts(cfg.num_patches + 1, cfg.depth, schedule)
+    total = 2.0 * cfg.num_patches * (cfg.in_chans * cfg.patch_size ** 2) * C + 2.0 * C * cfg.num_classes
+    for i, n in enumerate(counts):
+        npk = keep_count(schedule[i]["keep_ratio"], n) + 1 if i in schedule else n
+        total += 2.0 * n * C * 3 * C            # qkv on all N tokens
+        total += 4.0 * npk * npk * C            # QK^T and PV on kept tokens
+        total += 2.0 * npk * C * C              # proj
+        total += 4.0 * npk * C * Hd             # fc1 + fc2
+    return total, counts
+
+
+def cpu_baseline(cfg, schedule, seconds_budget=20.0):
+    """Oracle (numpy port of the reference algorithm) on the host cores, fp32, same model/schedule."""
+    from oracle import rajni_oracle as orc
+    from rajni_amd import timm_shaped as ts
+    sd = ts.synth_state_dict(cfg, seed=0)
+    rng = np.random.default_rng(1234)
+    bsz = 8
+    imgs = rng.standard_normal((bsz, 3, cfg.img_size, cfg.img_size), dtype=np.float32)
+    run = lambda: orc.vit_forward(sd, imgs, schedule, depth=cfg.depth, num_heads=cfg.num_heads,
+                                  ln_eps=cfg.ln_eps, dtype=np.float32)
+    run()  # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        run()
+        n += bsz
+        dt = time.time() - t0
+        if dt > seconds_budget or n >= 256:
+            break
+    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} synthetic 3x{cfg.img_size}x{cfg.img_size} images in batches of {bsz}, "
+                      f"same model dims and README schedule, fp32 numpy oracle (OpenBLAS threads = all cores), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--model", default="vit_base_patch16_224")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import rajni_amd
+    from rajni_amd import timm_shaped as ts, _native as nat
+
+    cfg = ts.CONFIGS[args.model]
+    schedule = README_SCHEDULE
+    B = args.batch
+    model = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev)
+    wrapped = rajni_amd.RAJNIViTWrapper(model, schedule).eval()
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=gen, device=dev).to(torch.bfloat16)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        wrapped(images)
+    gemm_mask = 0b0111  # the three packed-token GEMM instantiations
+    nat.profile_reset()
+    nat.profile_enable(gemm_mask)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wrapped(images)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nat.profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = nat.profile_collect()
+    counts = wrapped.get_last_stats()["token_counts"]
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    fl_img, _ = flops_per_image(cfg, schedule)
+    value = world * B * args.steps / elapsed
+    # dominant kernel = the GEMM instantiation with the most time
+    roofline = None
+    if prof:
+        name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = rec["ms"] / rec["launches"]
+        achieved = rec["flops"] / rec["launches"] / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": rec["launches"],
+                    "all_gemm": {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
+                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in prof.items()}}
+
+    out = {"metric": "images/sec ViT-B/16@224 with README schedule", "value": round(value, 1), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"{args.model} bf16, batch {B}/GPU, README 4-stage schedule "
+                                  f"{{3:.88,4:.88,7:.80,8:.72}}, synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
+                                  "random-init weights (seed 0)",
+                      "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}"},
+           "model_tflops": round(value * fl_img / 1e12, 1),
+           "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+           "roofline": roofline}
+
+    if world == 1 and not args.no_torch_baseline:
+        # the "4x" denominator: unpruned timm-shaped base, stock PyTorch-ROCm ops, same batch
+        base = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev).eval()
+        with torch.no_grad():
+            for _ in range(3):
+                base(images)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            nb = max(3, min(args.steps, 10))
+            for _ in range(nb):
+                base(images)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter() - t0
+        base_ips = B * nb / tb
+        out["unpruned_torch_images_per_sec"] = round(base_ips, 1)
+        out["speedup_vs_unpruned_torch"] = round(value / base_ips, 3)
+        del base
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, schedule, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

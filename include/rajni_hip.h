@@ -1,0 +1,170 @@
+/*
+ * rajni_hip.h - C ABI of librajni_hip.so: the MI355X (gfx950) token-pruning forward path.
+ *
+ * The reference (dRaniwal/RAJNI-ViT) has no FFI of its own: its hot path is Python calling ATen
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces a *Python* call site of the reference,
+ * cited as file:line relative to /root/reference/rajni/.  Conventions:
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns all buffers, nothing is allocated or freed inside, no host sync inside;
+ *   - every launch goes to the hipStream_t given (pass torch's current stream);
+ *   - returns RAJNI_OK (0) or an error code; rajni_last_error() gives a host string (thread local);
+ *   - `dtype` is the activation/weight element type.  RAJNI_BF16 is the implemented compute type
+ *     (fp32 accumulation everywhere); RAJNI_F32 returns RAJNI_ERR_UNSUPPORTED where not built.
+ *   - activations are row-major [B, N, C]; qkv is [B, N, 3*C] with the last axis laid out
+ *     [3][H][D] (timm convention; importance.py:14, attention.py:46-47);
+ *   - keep_idx is int32 on the device ([B, keep+1], slot 0 = CLS = 0, rest ascending); the Python
+ *     surface widens to int64 to match attention.py:38.
+ */
+#ifndef RAJNI_HIP_H
+#define RAJNI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rajni_stream_t; /* hipStream_t */
+
+enum { RAJNI_F32 = 0, RAJNI_BF16 = 1 };
+
+enum {
+  RAJNI_OK = 0,
+  RAJNI_ERR_INVALID = 1,     /* bad argument (null pointer, shape, alignment) */
+  RAJNI_ERR_UNSUPPORTED = 2, /* valid request the build does not implement (dtype, head dim ...) */
+  RAJNI_ERR_LAUNCH = 3       /* HIP runtime error at launch */
+};
+
+/* epilogues of rajni_linear */
+enum {
+  RAJNI_EPI_BIAS = 0,      /* y = x W^T + b                                  attention.py:22 (qkv) */
+  RAJNI_EPI_BIAS_GELU = 1, /* y = gelu_erf(x W^T + b)                        model.py:59 (mlp.fc1+act) */
+  RAJNI_EPI_BIAS_RESID = 2 /* y = resid[row or gathered row] + gamma*(x W^T + b)
+                              attention.py:55 + model.py:55-58 (proj, gather x, ls1, add);
+                              model.py:59 (mlp.fc2, ls2, add)                                       */
+};
+
+int rajni_abi_version(void);
+const char* rajni_last_error(void);
+/* 0 when a gfx950 device is usable by this process, else an error code (message in last_error) */
+int rajni_device_check(void);
+
+/* ---- a1: compute_importance(qkv, num_heads, eps)                         importance.py:4-34 ----
+ * scores_out [B,N] in `dtype` (the reference returns qkv's dtype, importance.py:34). */
+int rajni_importance(const void* qkv, void* scores_out, int B, int N, int H, int D, float eps,
+                     int dtype, rajni_stream_t stream);
+
+/* ---- a5,a6,a10: top-k + sort + CLS prepend + score carry                 attention.py:31-39,58 ----
+ * scores [B,N] in `dtype`; keep = max(1, int(keep_ratio*(N-1))) is computed by the caller
+ * (attention.py:31-32, Python-double semantics).  Tie rule (the reference leaves it unspecified):
+ * larger score first, then lower index; NaN ranks as +inf.
+ * keep_idx [B,keep+1] int32; next_scores [B,keep+1] in `dtype` (may be NULL). */
+int rajni_select_topk(const void* scores, int B, int N, int keep, int32_t* keep_idx,
+                      void* next_scores, int dtype, rajni_stream_t stream);
+
+/* ---- a1+a6+a10 fused (one launch per pruning stage): scores never leave the chip between the
+ * two steps.  scores_out may be NULL. */
+int rajni_score_select(const void* qkv, int B, int N, int H, int D, float eps, int keep,
+                       void* scores_out, int32_t* keep_idx, void* next_scores, int dtype,
+                       rajni_stream_t stream);
+
+/* ---- a7,a13: torch.gather(t, 1, keep_idx[..., None].expand(...))   attention.py:42-43, model.py:55-56
+ * src [B,n_src,row_elems] -> dst [B,n_dst,row_elems]; row_elems*elem_size must be a multiple of 16. */
+int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int n_src, int n_dst,
+                      int row_elems, int dtype, rajni_stream_t stream);
+
+/* ---- a8: softmax(q k^T * scale) v on the kept tokens                      attention.py:46-54 ----
+ * qkv [B,n_src,3*H*D]; keep_idx [B,np] int32 or NULL (NULL: identity, np == n_src - the unpruned
+ * block of model.py:62).  The row gather of attention.py:42-43 is fused into the tile loads.
+ * out [B,np,H*D].  D must be 64. */
+int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
+                    int H, int D, float scale, int dtype, rajni_stream_t stream);
+
+/* ---- LayerNorm over the last axis (blk.norm1 / norm2 / m.norm)            model.py:51,59,65 ----
+ * x rows are `x_row_stride` elements apart (lets the final norm read CLS rows only), y is dense
+ * [rows, C].  w,b are fp32 [C]. C % 8 == 0. */
+int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,
+                    int rows, int C, float eps, int dtype, rajni_stream_t stream);
+
+/* ---- linear layers with fused epilogues (a3, a9, a13, a15) ----
+ * y[M,N] = epi(x[M,K] W[N,K]^T).  W must be allocated with its row count padded up to a multiple
+ * of 128 (rows >= N are never read into results but must be readable); K % 64 == 0; lda/ldw/ldc/ldr
+ * in elements, multiples of 8.  bias/gamma are fp32 [N] (NULL = 0 / 1).
+ * RESID: resid row for output row m is  (m / r_np) * r_nsrc + r_idx[m]  when r_idx != NULL
+ * (r_idx = keep_idx flattened [B*r_np]), else m. */
+typedef struct {
+  const void* x; long lda;
+  const void* w; long ldw;
+  const float* bias;
+  const float* gamma;
+  const void* resid; long ldr;
+  const int32_t* r_idx; int r_np; int r_nsrc;
+  void* y; long ldc;
+  int M, N, K;
+  int epilogue;
+  int dtype;
+} rajni_linear_args;
+int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
+
+/* ---- a12: patch-embed + CLS + pos-embed                                    model.py:34-37 ----
+ * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad128), Cin*P*P] (k order c,ky,kx),
+ * bias fp32 [C]; cls [C]; pos [(1 or 0)+(S/P)^2, C] (`pos_has_cls`=0 is timm no_embed_class:
+ * SURVEY B3).  The im2col is fused into the GEMM's tile loads.  P % 8 == 0, S % P == 0. */
+int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
+                      const void* pos, int pos_has_cls, void* x, int B, int Cin, int S, int P,
+                      int C, int dtype, rajni_stream_t stream);
+
+/* ---- a11-a16: the whole RAJNIViTWrapper.forward                            model.py:30-69 ---- */
+typedef struct {
+  const float* norm1_w; const float* norm1_b;
+  const void* qkv_w; const float* qkv_b;      /* [3C(pad),C], [3C] */
+  const void* proj_w; const float* proj_b;    /* [C(pad),C], [C]  */
+  const float* ls1;                           /* [C] or NULL      */
+  const float* norm2_w; const float* norm2_b;
+  const void* fc1_w; const float* fc1_b;      /* [Hd(pad),C], [Hd] */
+  const void* fc2_w; const float* fc2_b;      /* [C(pad),Hd], [C]  */
+  const float* ls2;
+  /* schedule entry for this block (model.py:13-20): keep = 0 -> not scheduled (model.py:62) */
+  int keep;                /* kept PATCH tokens (attention.py:31-32), output has keep+1 tokens */
+  int update;              /* attention.py:25: recompute scores iff update or no carried scores */
+  int32_t* keep_idx;       /* [B,keep+1] out (required when keep>0) */
+  void* scores;            /* [B,N] out, dtype (optional) */
+  void* next_scores;       /* [B,keep+1] out, dtype (required when keep>0: carried to the next block) */
+  const int32_t* forced_keep_idx; /* test hook: use this selection instead (selection-conditional parity) */
+} rajni_block;
+
+typedef struct {
+  int dtype;
+  int B, in_chans, img_size, patch_size;
+  int C, H, D, depth, hidden, num_classes;
+  float ln_eps, attn_scale;
+  int pos_has_cls;
+  const void* patch_w; const float* patch_b; const void* cls_token; const void* pos_embed;
+  const rajni_block* blocks;                   /* host array [depth] */
+  const float* norm_w; const float* norm_b;
+  const void* head_w; const float* head_b;     /* [classes(pad),C], [classes] */
+  void* workspace; size_t workspace_bytes;     /* >= rajni_vit_workspace_bytes() */
+  int32_t* token_counts;                       /* HOST int32[depth] out: tokens at block entry (model.py:43) */
+  int logits_ld;                               /* row stride of `logits` in elements (0 = num_classes); % 8 == 0 */
+} rajni_vit_plan;
+
+size_t rajni_vit_workspace_bytes(const rajni_vit_plan* plan);
+/* images [B,Cin,S,S] dtype; logits [B,num_classes] dtype */
+int rajni_vit_forward(const rajni_vit_plan* plan, const void* images, void* logits,
+                      rajni_stream_t stream);
+
+/* ---- measurement hooks (bench.py roofline): HIP-event timing per kernel class on the launch
+ * stream.  mask bit i enables class i; classes listed by rajni_profile_class_name(). ---- */
+enum { RAJNI_NUM_KCLASS = 12 };
+void rajni_profile_enable(unsigned mask);
+const char* rajni_profile_class_name(int kclass);
+/* synchronises the recorded events, ADDS them into the accumulators, returns them: per class the
+ * number of launches, total milliseconds, algorithmic flops and algorithmic bytes. */
+int rajni_profile_collect(long long* launches, double* ms, double* flops, double* bytes);
+void rajni_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAJNI_HIP_H */

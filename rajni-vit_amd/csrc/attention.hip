@@ -1,0 +1,213 @@
+// Fused softmax attention on the packed (kept) tokens, head dim 64  (reference
+// attention.py:42-54).  The keep_idx row gather is fused into the Q/K/V tile loads: nothing of the
+// reference's gathered qkv copy or its [B,H,Np,Np] attention matrix ever reaches HBM.
+//
+// Work split: grid (ceil(Np/128), H, B); a workgroup = 4 waves, each wave owns 32 query rows.
+// K/V of the (image, head) are staged through LDS in chunks of 128 keys (16 KiB + 16 KiB, swizzled
+// for conflict-free reads); online softmax over 32-key sub-blocks in fp32.
+//
+// MFMA orientation ("key/feature on the register axis, query on the lane"):
+//   S^T[key][q] = K Q^T        v_mfma_f32_32x32x16_bf16(A = K rows from LDS, B = Q rows from registers)
+//   O^T[d][q]  += V^T P^T      A = V^T via ds_read_b64_tr_b16 (hardware transpose of row-major V),
+//                              B = the S^T accumulator itself, exponentiated and packed to bf16 -
+//                              an accumulator tile is directly the next MFMA's B operand, so P never
+//                              goes through LDS or lane shuffles.
+// Every per-query quantity (running max, sum, rescale factor, 1/l) is per-lane.
+#include "common.h"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_QROWS = 128;    // query rows per workgroup
+constexpr int KV_CHUNK = 128;    // keys per LDS chunk
+constexpr int AT_LDS = 2 * KV_CHUNK * 128;  // K + V tiles, 128-byte rows
+
+struct AttnArgs {
+  const bf16_t* qkv;
+  const int* idx;   // [B,np] or null
+  bf16_t* out;      // [B,np,H*64]
+  int n_src, np, H;
+  float c;          // scale * log2(e)
+};
+
+__device__ __forceinline__ int k_off(int row, int chunk) {   // K tile: natural row reads
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ int v_off(int row, int chunk) {   // V tile: 4-row x 64-byte tr blocks
+  return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4);
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* sv, int row, int col) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int o0 = v_off(row, col >> 3) + (col & 7) * 2;
+  const int o1 = v_off(row + 8, col >> 3) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sv + o0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sv + o1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(AT_THREADS) attn_bf16_d64(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[AT_LDS];
+  char* sk = smem;
+  char* sv = smem + KV_CHUNK * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5, g = lane >> 4, l15 = lane & 15;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int np = a.np, C = a.H * 64, C3 = 3 * C;
+  const bf16_t* img = a.qkv + (long)b * a.n_src * C3;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+
+  const int qbase = blockIdx.x * AT_QROWS + wave * 32;
+  const bool active = qbase < np;
+
+  // ---- Q fragments straight from HBM (B operand: lane holds Q[q = l31][d = 16s + 8h .. +7])
+  bf16x8 qf[4];
+  {
+    int q = qbase + l31;
+    if (q > np - 1) q = np - 1;
+    const int srow = idx ? idx[q] : q;
+    const bf16_t* qp = img + (long)srow * C3 + head * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int st_c = tid & 7, st_r = tid >> 3;  // staging: 8 threads per 128-byte row, 32 rows per pass
+
+  for (int c0 = 0; c0 < np; c0 += KV_CHUNK) {
+    // ---- stage K and V rows c0 .. c0+127 (gathered through keep_idx), zero-fill past np
+    uint4 kreg[4], vreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = c0 + st_r + 32 * i;
+      if (t < np) {
+        const int srow = idx ? idx[t] : t;
+        const bf16_t* rp = img + (long)srow * C3 + head * 64 + st_c * 8;
+        kreg[i] = *reinterpret_cast<const uint4*>(rp + C);
+        vreg[i] = *reinterpret_cast<const uint4*>(rp + 2 * C);
+      } else {
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        vreg[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = st_r + 32 * i;
+      *reinterpret_cast<uint4*>(sk + k_off(row, st_c)) = kreg[i];
+      *reinterpret_cast<uint4*>(sv + v_off(row, st_c)) = vreg[i];
+    }
+    __syncthreads();
+
+    if (active) {
+      const int nsub = (np - c0 + 31) >> 5;
+      for (int kb = 0; kb < 4 && kb < nsub; ++kb) {
+        // ---- S^T tile: 32 keys x 32 queries
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const int krow = kb * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(krow, 2 * ks + h));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        const int nvalid = np - c0 - kb * 32;  // keys of this sub-block that exist
+        if (nvalid < 32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (kr >= nvalid) s[r] = -INFINITY;
+          }
+        }
+        // ---- online softmax; lane = query, registers (+ the other half-wave) = keys
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * a.c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float p[16];
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c, -m_new));
+          lsum += p[r];
+        }
+        l_run = fmaf(l_run, alpha, lsum);
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // ---- P^T (bf16) as the B operand: registers 8s .. 8s+7 feed k-step s; element j of half h
+        //      is key 16s + 8(j>>2) + 4h + (j&3) - V^T below is read in that same key order
+        bf16x8 pb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          const u32x4 w = {pack2bf(p[8 * s2 + 0], p[8 * s2 + 1]), pack2bf(p[8 * s2 + 2], p[8 * s2 + 3]),
+                           pack2bf(p[8 * s2 + 4], p[8 * s2 + 5]), pack2bf(p[8 * s2 + 6], p[8 * s2 + 7])};
+          pb[s2] = __builtin_bit_cast(bf16x8, w);
+        }
+        // ---- O^T += V^T P^T ; lane (d = l31 of the d-tile, half h) needs keys 16s+4h+{0..3} and +8
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int key0 = kb * 32 + 16 * s2 + 4 * h + (l15 >> 2);
+          const int col = 16 * (g & 1) + 4 * (l15 & 3);
+          const bf16x8 v0 = tr_pair(sv, key0, col);
+          const bf16x8 v1 = tr_pair(sv, key0, 32 + col);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb[s2], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb[s2], o1, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (!active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = qbase + l31;
+  if (q < np) {
+    bf16_t* op = a.out + ((long)b * np + q) * C + head * 64 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // registers 4t..4t+3 of a d-tile are d = 8t + 4h + {0..3}
+      uint2 w0, w1;
+      w0.x = pack2bf(o0[4 * t] * inv, o0[4 * t + 1] * inv);
+      w0.y = pack2bf(o0[4 * t + 2] * inv, o0[4 * t + 3] * inv);
+      w1.x = pack2bf(o1[4 * t] * inv, o1[4 * t + 1] * inv);
+      w1.y = pack2bf(o1[4 * t + 2] * inv, o1[4 * t + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 8 * t) = w0;
+      *reinterpret_cast<uint2*>(op + 32 + 8 * t) = w1;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
+                     int H, int D, float scale, hipStream_t s) {
+  RAJNI_REQUIRE(qkv && out, RAJNI_ERR_INVALID, "rajni_attention: null pointer");
+  RAJNI_REQUIRE(D == 64, RAJNI_ERR_UNSUPPORTED, "rajni_attention: head dim %d not built (64 only)", D);
+  RAJNI_REQUIRE(B > 0 && H > 0 && np > 0 && n_src >= np, RAJNI_ERR_INVALID,
+                "rajni_attention: bad shape B=%d H=%d np=%d n_src=%d", B, H, np, n_src);
+  RAJNI_REQUIRE(keep_idx != nullptr || np == n_src, RAJNI_ERR_INVALID,
+                "rajni_attention: identity selection needs np == n_src");
+  RAJNI_REQUIRE(H <= 65535 && B <= 65535, RAJNI_ERR_UNSUPPORTED, "rajni_attention: grid too large");
+  AttnArgs a{};
+  a.qkv = (const bf16_t*)qkv; a.idx = keep_idx; a.out = (bf16_t*)out;
+  a.n_src = n_src; a.np = np; a.H = H;
+  a.c = scale * 1.4426950408889634f;
+  const double flops = 4.0 * B * H * (double)np * np * D;
+  const double bytes = 2.0 * B * (double)np * H * D * 4.0;
+  ProfScope prof(KC_ATTENTION, s, flops, bytes);
+  hipLaunchKernelGGL(attn_bf16_d64, dim3((np + AT_QROWS - 1) / AT_QROWS, H, B), dim3(AT_THREADS), 0,
+                     s, a);
+  RAJNI_CHECK_LAUNCH("attn_bf16_d64");
+  return RAJNI_OK;
+}

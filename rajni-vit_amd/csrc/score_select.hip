@@ -1,0 +1,273 @@
+// RAJNI importance score + per-image top-k selection + order-preserving compaction
+// (SURVEY k3-k9,k14; reference importance.py:4-34, attention.py:31-39,58) in ONE launch per stage.
+//
+// One 512-thread workgroup per image.  HBM traffic = the K and V thirds of qkv, read once with
+// 16-byte loads; logits, head-mean V, norms and scores live in LDS; selection is a rank count
+// (N <= 577 scores, broadcast LDS reads) followed by wave ballot + popcount prefix compaction, which
+// yields the ascending index list directly (the reference's topk -> sort).
+//
+// Numerics: fp32 throughout; the final score is rounded to the I/O dtype (what the reference
+// returns, importance.py:34) and ranking is done on the rounded values - like the reference ranks
+// its own dtype-rounded scores - with the DEFINED tie rule: larger first, then lower index; NaN = +inf.
+// All reductions use fixed trees, so the same input always selects the same tokens.
+#include "common.h"
+
+namespace {
+
+constexpr int SS_THREADS = 512;
+
+struct ScoreArgs {
+  const bf16_t* qkv;        // [B,N,3C] or null (select-only)
+  const bf16_t* scores_in;  // [B,N] (select-only)
+  int N, H, D;
+  float eps;
+  int keep;                 // 0: scores only
+  bf16_t* scores_out;       // [B,N] or null
+  int* keep_idx;            // [B,keep+1]
+  bf16_t* next_scores;      // [B,keep+1] or null
+};
+
+__device__ __forceinline__ float rank_key(float s) { return (s != s) ? INFINITY : s; }
+
+template <bool COMPUTE>
+__global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const int N = a.N, H = a.H, D = a.D, C = H * D;
+  const int region_sz = (H * N > N * D) ? H * N : N * D;
+  float* qcls = sm;                    // [C]
+  float* region = qcls + C;            // logits [H][N]  then  vbar [N][D]
+  float* acls = region + region_sz;    // [N]
+  float* sc = acls + N;                // vnorm [N] then scores [N]
+  float* hstat = sc + N;               // [2H]
+  float* part = hstat + 2 * H;         // [SS_THREADS]
+  float* mean = part + SS_THREADS;     // [D]
+  float* misc = mean + D;              // [16]
+  int* wcount = reinterpret_cast<int*>(misc + 16);  // [8]
+
+  if (COMPUTE) {
+    const bf16_t* base = a.qkv + (long)b * N * 3 * C;
+    const int LP = D >> 3;             // lanes per 2*D-byte head row
+    const int sub = tid & (LP - 1);
+    const int grp = tid / LP, ngrp = SS_THREADS / LP;
+
+    // ---- CLS query row -> LDS (importance.py:18)
+    for (int c = tid; c < (C >> 3); c += SS_THREADS) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + c * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qcls[c * 8 + j] = f[j];
+    }
+    __syncthreads();
+
+    // ---- logits[h][n] = q_cls[h] . k[n,h] / sqrt(D)   (importance.py:19)
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    for (int pair = grp; pair < N * H; pair += ngrp) {
+      const int n = pair / H, h = pair - n * H;
+      float kf[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + (long)n * 3 * C + C + h * D + sub * 8), kf);
+      const float* qh = qcls + h * D + sub * 8;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot = fmaf(kf[j], qh[j], dot);
+      for (int o = LP >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+      if (sub == 0) region[h * N + n] = dot * inv_sqrt_d;
+    }
+    __syncthreads();
+
+    // ---- per-head softmax statistics over ALL N tokens (importance.py:20)
+    for (int h = wave; h < H; h += SS_THREADS / 64) {
+      float mx = -INFINITY;
+      for (int n = lane; n < N; n += 64) mx = fmaxf(mx, region[h * N + n]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int n = lane; n < N; n += 64) se += __expf(region[h * N + n] - mx);
+      se = wave_sum(se);
+      if (lane == 0) { hstat[h] = mx; hstat[H + h] = se; }
+    }
+    __syncthreads();
+    // ---- A_cls[n] = mean_h softmax_h[n]   (importance.py:21)
+    for (int n = tid; n < N; n += SS_THREADS) {
+      float s = 0.f;
+      for (int h = 0; h < H; ++h) s += __expf(region[h * N + n] - hstat[h]) / hstat[H + h];
+      acls[n] = s / (float)H;
+    }
+    __syncthreads();  // logits are dead: region becomes vbar
+
+    // ---- vbar[n][:] = mean_h v[n,h,:]   (importance.py:24)
+    const float inv_h = 1.0f / (float)H;
+    for (int n = grp; n < N; n += ngrp) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const bf16_t* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
+      for (int h = 0; h < H; ++h) {
+        float vf[8];
+        unpack8(*reinterpret_cast<const uint4*>(vp + h * D), vf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += vf[j];
+      }
+      float* dst = region + n * D + sub * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = acc[j] * inv_h;
+    }
+    __syncthreads();
+    // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
+    {
+      const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;
+      float s = 0.f;
+      for (int n = prt; n < N; n += nparts) s += region[n * D + d];
+      part[prt * D + d] = s;
+      __syncthreads();
+      if (tid < D) {
+        float t = 0.f;
+        for (int q = 0; q < nparts; ++q) t += part[q * D + tid];
+        mean[tid] = t / (float)N;
+      }
+      __syncthreads();
+    }
+    // ---- ||vbar[n] - mean||_2   (importance.py:27)
+    for (int n = grp; n < N; n += ngrp) {
+      const float* src = region + n * D + sub * 8;
+      const float* mp = mean + sub * 8;
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dlt = src[j] - mp[j];
+        ss = fmaf(dlt, dlt, ss);
+      }
+      for (int o = LP >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      if (sub == 0) sc[n] = sqrtf(ss);
+    }
+    __syncthreads();
+    // ---- mu, unbiased std + eps over tokens   (importance.py:28-29)
+    if (wave == 0) {
+      float s = 0.f;
+      for (int n = lane; n < N; n += 64) s += sc[n];
+      const float mu = wave_sum(s) / (float)N;
+      float ss = 0.f;
+      for (int n = lane; n < N; n += 64) {
+        const float dlt = sc[n] - mu;
+        ss = fmaf(dlt, dlt, ss);
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) {
+        misc[0] = mu;
+        misc[1] = sqrtf(ss / (float)(N - 1)) + a.eps;
+      }
+    }
+    __syncthreads();
+    // ---- score = A_cls * sigmoid(z), rounded to the I/O dtype   (importance.py:31-34)
+    {
+      const float mu = misc[0], sd = misc[1];
+      for (int n = tid; n < N; n += SS_THREADS) {
+        const float z = (sc[n] - mu) / sd;
+        const float sig = 1.0f / (1.0f + __expf(-z));
+        const bf16_t sb = f2bf(acls[n] * sig);
+        if (a.scores_out != nullptr) a.scores_out[(long)b * N + n] = sb;
+        sc[n] = bf2f(sb);
+      }
+    }
+    __syncthreads();
+  } else {
+    for (int n = tid; n < N; n += SS_THREADS) sc[n] = bf2f(a.scores_in[(long)b * N + n]);
+    __syncthreads();
+  }
+
+  if (a.keep <= 0) return;
+
+  // ---- rank patch tokens 1..N-1, keep rank < keep, compact in ascending index order
+  //      (attention.py:34-39: topk -> sort -> +1 -> prepend CLS; attention.py:58: carried scores)
+  const int keep = a.keep;
+  int* kout = a.keep_idx + (long)b * (keep + 1);
+  bf16_t* nout = a.next_scores ? a.next_scores + (long)b * (keep + 1) : nullptr;
+  int running = 0;
+  for (int base_i = 1; base_i < N; base_i += SS_THREADS) {
+    const int i = base_i + tid;
+    const bool valid = i < N;
+    bool kept = false;
+    float si = 0.f;
+    if (valid) {
+      si = sc[i];
+      const float ki = rank_key(si);
+      int rank = 0;
+      for (int j = 1; j < N; ++j) {
+        const float kj = rank_key(sc[j]);
+        rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+      }
+      kept = rank < keep;
+    }
+    const unsigned long long bal = __ballot(kept);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SS_THREADS / 64; ++w) {
+      const int cnt = wcount[w];
+      prefix += (w < wave) ? cnt : 0;
+      total += cnt;
+    }
+    if (kept) {
+      const int pos = running + prefix + __popcll(bal & ((1ull << lane) - 1ull));
+      kout[1 + pos] = i;
+      if (nout) nout[1 + pos] = f2bf(si);
+    }
+    running += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    kout[0] = 0;
+    if (nout) nout[0] = f2bf(sc[0]);
+  }
+}
+
+size_t ss_lds_bytes(int N, int H, int D) {
+  const size_t C = (size_t)H * D;
+  const size_t region = (size_t)((H * N > N * D) ? H * N : N * D);
+  return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_THREADS + D + 16 + 8) * sizeof(float);
+}
+
+}  // namespace
+
+// qkv != null: compute scores (and select when keep > 0); qkv == null: select from scores_in.
+int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
+                        float eps, int keep, void* scores_out, int32_t* keep_idx,
+                        void* next_scores, hipStream_t s) {
+  RAJNI_REQUIRE(B > 0 && N >= 2, RAJNI_ERR_INVALID, "score/select: need B > 0 and N >= 2 (B=%d N=%d)", B, N);
+  RAJNI_REQUIRE(keep >= 0 && keep <= N - 1, RAJNI_ERR_INVALID,
+                "score/select: keep=%d out of range for N=%d (keep_ratio must be <= 1)", keep, N);
+  RAJNI_REQUIRE(keep == 0 || keep_idx != nullptr, RAJNI_ERR_INVALID, "score/select: keep_idx is null");
+  ScoreArgs a{};
+  a.N = N; a.keep = keep; a.eps = eps;
+  a.scores_out = (bf16_t*)scores_out; a.keep_idx = keep_idx; a.next_scores = (bf16_t*)next_scores;
+  size_t lds;
+  if (qkv != nullptr) {
+    RAJNI_REQUIRE(D == 32 || D == 64 || D == 128, RAJNI_ERR_UNSUPPORTED,
+                  "importance: head dim %d not supported (32/64/128)", D);
+    RAJNI_REQUIRE(H > 0, RAJNI_ERR_INVALID, "importance: H must be positive");
+    a.qkv = (const bf16_t*)qkv; a.H = H; a.D = D;
+    lds = ss_lds_bytes(N, H, D);
+  } else {
+    RAJNI_REQUIRE(scores_in != nullptr, RAJNI_ERR_INVALID, "select: scores is null");
+    a.scores_in = (const bf16_t*)scores_in; a.H = 1; a.D = 32;
+    lds = ss_lds_bytes(N, 1, 32);
+  }
+  RAJNI_REQUIRE(lds <= 160 * 1024, RAJNI_ERR_UNSUPPORTED,
+                "score/select: N=%d H=%d D=%d needs %zu B of LDS (> 160 KiB)", N, H, D, lds);
+  const void* fn = qkv ? reinterpret_cast<const void*>(&score_select_kernel<true>)
+                       : reinterpret_cast<const void*>(&score_select_kernel<false>);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      rajni_set_error("hipFuncSetAttribute(score_select, %zu): %s", lds, hipGetErrorString(e));
+      return RAJNI_ERR_LAUNCH;
+    }
+  }
+  const double bytes = qkv ? (2.0 * N * H * D + H * D) * 2.0 * B + 4.0 * N * B : 6.0 * N * B;
+  ProfScope prof(qkv ? (keep > 0 ? KC_SCORE_SELECT : KC_IMPORTANCE) : KC_SELECT, s, 0.0, bytes);
+  if (qkv)
+    hipLaunchKernelGGL(score_select_kernel<true>, dim3(B), dim3(SS_THREADS), lds, s, a);
+  else
+    hipLaunchKernelGGL(score_select_kernel<false>, dim3(B), dim3(SS_THREADS), lds, s, a);
+  RAJNI_CHECK_LAUNCH("score_select_kernel");
+  return RAJNI_OK;
+}

@@ -1,0 +1,167 @@
+"""Tensor-level entry points over the C ABI (one function per `rajni_*` symbol of
+include/rajni_hip.h).  They only validate, allocate outputs with torch, and pass raw pointers plus
+torch's current stream; all compute is in librajni_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nat
+
+
+def keep_count(keep_ratio: float, n_tokens: int) -> int:
+    """`keep = max(1, int(keep_ratio * (N - 1)))` - Python-double semantics of the reference
+    (rajni/wrapper/attention.py:31-32); data independent."""
+    return max(1, int(keep_ratio * (n_tokens - 1)))
+
+
+def _dt(t: torch.Tensor) -> int:
+    return nat.dtype_code(t.dtype)
+
+
+def pack_weight(w: torch.Tensor, dtype=torch.bfloat16, device=None) -> torch.Tensor:
+    """[N, K...] Linear/Conv weight -> contiguous [ceil128(N), K] in `dtype`, zero padded rows
+    (the GEMM stages whole 128-row W tiles)."""
+    n = w.shape[0]
+    w2 = w.detach().reshape(n, -1)
+    npad = (n + 127) // 128 * 128
+    out = torch.zeros((npad, w2.shape[1]), dtype=dtype, device=device if device is not None else w.device)
+    out[:n].copy_(w2)
+    return out
+
+
+def pack_vec(v: Optional[torch.Tensor], like_dtype=torch.bfloat16, device=None) -> Optional[torch.Tensor]:
+    """bias / LayerNorm / LayerScale vector -> fp32 copy of the value the model dtype holds."""
+    if v is None:
+        return None
+    return v.detach().to(like_dtype).to(torch.float32).to(device if device is not None else v.device).contiguous()
+
+
+def importance(qkv: torch.Tensor, num_heads: int, eps: float = 1e-6) -> torch.Tensor:
+    nat.require_device(qkv, "qkv")
+    qkv = qkv.contiguous()
+    B, N, threeC = qkv.shape
+    D = threeC // 3 // num_heads
+    out = torch.empty((B, N), dtype=qkv.dtype, device=qkv.device)
+    nat.check(nat.lib().rajni_importance(qkv.data_ptr(), out.data_ptr(), B, N, num_heads, D, eps, _dt(qkv),
+                                         nat.stream_ptr(qkv.device)), "rajni_importance")
+    return out
+
+
+def select_topk(scores: torch.Tensor, keep: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    nat.require_device(scores, "scores")
+    scores = scores.contiguous()
+    B, N = scores.shape
+    idx = torch.empty((B, keep + 1), dtype=torch.int32, device=scores.device)
+    nxt = torch.empty((B, keep + 1), dtype=scores.dtype, device=scores.device)
+    nat.check(nat.lib().rajni_select_topk(scores.data_ptr(), B, N, keep, idx.data_ptr(), nxt.data_ptr(),
+                                          _dt(scores), nat.stream_ptr(scores.device)), "rajni_select_topk")
+    return idx, nxt
+
+
+def score_select(qkv: torch.Tensor, num_heads: int, keep: int, eps: float = 1e-6, want_scores: bool = True):
+    nat.require_device(qkv, "qkv")
+    qkv = qkv.contiguous()
+    B, N, threeC = qkv.shape
+    D = threeC // 3 // num_heads
+    scores = torch.empty((B, N), dtype=qkv.dtype, device=qkv.device) if want_scores else None
+    idx = torch.empty((B, keep + 1), dtype=torch.int32, device=qkv.device)
+    nxt = torch.empty((B, keep + 1), dtype=qkv.dtype, device=qkv.device)
+    nat.check(nat.lib().rajni_score_select(qkv.data_ptr(), B, N, num_heads, D, eps, keep, nat.ptr(scores),
+                                           idx.data_ptr(), nxt.data_ptr(), _dt(qkv),
+                                           nat.stream_ptr(qkv.device)), "rajni_score_select")
+    return scores, idx, nxt
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """src [B, N, E], idx [B, K] int32 -> [B, K, E]"""
+    nat.require_device(src, "src")
+    src = src.contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    B, N, E = src.shape
+    K = idx.shape[1]
+    out = torch.empty((B, K, E), dtype=src.dtype, device=src.device)
+    nat.check(nat.lib().rajni_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, N, K, E, _dt(src),
+                                          nat.stream_ptr(src.device)), "rajni_gather_rows")
+    return out
+
+
+def attention(qkv: torch.Tensor, keep_idx: Optional[torch.Tensor], num_heads: int, scale: float) -> torch.Tensor:
+    """qkv [B, N, 3C]; keep_idx [B, Np] int32 or None -> [B, Np, C]"""
+    nat.require_device(qkv, "qkv")
+    qkv = qkv.contiguous()
+    B, N, threeC = qkv.shape
+    Cc = threeC // 3
+    D = Cc // num_heads
+    if keep_idx is not None:
+        keep_idx = keep_idx.to(torch.int32).contiguous()
+        Np = keep_idx.shape[1]
+    else:
+        Np = N
+    out = torch.empty((B, Np, Cc), dtype=qkv.dtype, device=qkv.device)
+    nat.check(nat.lib().rajni_attention(qkv.data_ptr(), nat.ptr(keep_idx), out.data_ptr(), B, N, Np, num_heads, D,
+                                        float(scale), _dt(qkv), nat.stream_ptr(qkv.device)), "rajni_attention")
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, rows: Optional[int] = None,
+              row_stride: Optional[int] = None) -> torch.Tensor:
+    """LayerNorm over the last axis; w, b fp32.  With rows/row_stride reads a strided subset of rows."""
+    nat.require_device(x, "x")
+    x = x.contiguous()
+    Cc = x.shape[-1]
+    if rows is None:
+        rows = x.numel() // Cc
+        row_stride = Cc
+        out = torch.empty_like(x)
+    else:
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    nat.check(nat.lib().rajni_layernorm(x.data_ptr(), row_stride, w.data_ptr(), b.data_ptr(), out.data_ptr(), rows,
+                                        Cc, float(eps), _dt(x), nat.stream_ptr(x.device)), "rajni_layernorm")
+    return out
+
+
+def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None,
+           epilogue: int = nat.EPI_BIAS, gamma: Optional[torch.Tensor] = None,
+           resid: Optional[torch.Tensor] = None, r_idx: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epi(x @ W^T): x [..., K]; w_packed from pack_weight(); bias/gamma fp32 [n_out].
+    resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID."""
+    nat.require_device(x, "x")
+    x = x.contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    ld = (n_out + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((M, ld), dtype=x.dtype, device=x.device)
+    a = nat.LinearArgs()
+    a.x, a.lda, a.w, a.ldw = x.data_ptr(), K, w_packed.data_ptr(), w_packed.shape[1]
+    a.bias, a.gamma = nat.ptr(bias), nat.ptr(gamma)
+    a.y, a.ldc = out.data_ptr(), out.shape[-1] if out.dim() == 2 else out.stride(-2)
+    a.M, a.N, a.K, a.epilogue, a.dtype = M, n_out, K, epilogue, _dt(x)
+    if resid is not None:
+        resid = resid.contiguous()
+        a.resid, a.ldr = resid.data_ptr(), resid.shape[-1]
+        if r_idx is not None:
+            r_idx = r_idx.to(torch.int32).contiguous()
+            a.r_idx, a.r_np, a.r_nsrc = r_idx.data_ptr(), r_idx.shape[1], resid.shape[1]
+    nat.check(nat.lib().rajni_linear(C.byref(a), nat.stream_ptr(x.device)), "rajni_linear")
+    y = out[:, :n_out] if ld != n_out else out
+    return y.reshape(*x.shape[:-1], n_out) if ld == n_out else y
+
+
+def patch_embed(images: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cls: torch.Tensor,
+                pos: torch.Tensor, pos_has_cls: bool, patch: int, embed_dim: int) -> torch.Tensor:
+    nat.require_device(images, "images")
+    images = images.contiguous()
+    B, Cin, S, _ = images.shape
+    n = (S // patch) ** 2 + 1
+    x = torch.empty((B, n, embed_dim), dtype=images.dtype, device=images.device)
+    nat.check(nat.lib().rajni_patch_embed(images.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), cls.data_ptr(),
+                                          pos.data_ptr(), int(pos_has_cls), x.data_ptr(), B, Cin, S, patch,
+                                          embed_dim, _dt(images), nat.stream_ptr(images.device)),
+              "rajni_patch_embed")
+    return x

@@ -1,0 +1,273 @@
+"""`RAJNIViTWrapper(base_model, pruning_schedule)` - drop-in for the reference wrapper
+(`rajni/wrapper/model.py:6-69`) whose forward runs as ONE native plan on the MI355X.
+
+Kept from the reference: constructor signature, in-place surgery on the base model (scheduled
+blocks get a `RAJNIAttention`, every block gets `has_pruner`; model.py:12-23), parameter sharing,
+`forward(images) -> logits`, `get_last_stats() -> {"token_counts": [...]}` (None before the first
+forward).  Deliberate fixes: schedule keys are normalised to int (B1: a JSON-loaded
+schedule prunes), and a `no_embed_class` pos-embed works (B3).
+
+Not kept: the Python per-block loop.  `forward` builds (once per batch shape) a `rajni_vit_plan`
+- packed weights, workspace, per-stage index buffers - and calls `rajni_vit_forward`, which enqueues
+every kernel of the network on the current stream with no host synchronisation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+from .. import ops
+from .attention import RAJNIAttention
+
+
+def normalise_schedule(schedule) -> Dict[int, Dict]:
+    """{block index: {"keep_ratio": float, "update": bool}} with int keys.  A missing `keep_ratio`
+    raises KeyError like the reference (model.py:18); `update` defaults to True (model.py:19)."""
+    out: Dict[int, Dict] = {}
+    for k, cfg in (schedule or {}).items():
+        out[int(k)] = {"keep_ratio": float(cfg["keep_ratio"]), "update": bool(cfg.get("update", True))}
+    return out
+
+
+def plan_token_counts(n0: int, depth: int, schedule: Dict[int, Dict]) -> List[int]:
+    """Tokens at the entry of every block (model.py:43) - a pure function of (N0, depth, schedule)."""
+    counts, n = [], n0
+    for i in range(depth):
+        counts.append(n)
+        if i in schedule:
+            n = ops.keep_count(schedule[i]["keep_ratio"], n) + 1
+    return counts
+
+
+class RAJNIViTWrapper(nn.Module):
+    def __init__(self, base_model: nn.Module, pruning_schedule: Dict[int, Dict]):
+        super().__init__()
+        self.m = base_model
+        self.blocks = base_model.blocks
+        self.pruning_schedule = normalise_schedule(pruning_schedule)
+
+        for i, blk in enumerate(self.blocks):
+            if i in self.pruning_schedule:
+                cfg = self.pruning_schedule[i]
+                if not isinstance(blk.attn, RAJNIAttention):
+                    blk.attn = RAJNIAttention(blk.attn, keep_ratio=cfg["keep_ratio"], update=cfg["update"])
+                else:  # re-wrapping an already wrapped base
+                    blk.attn.keep_ratio, blk.attn.update = cfg["keep_ratio"], cfg["update"]
+                blk.has_pruner = True
+            else:
+                blk.has_pruner = False
+
+        self._last_stats = None
+        self._weights = None       # packed device tensors (kept alive here)
+        self._weights_key = None
+        self._plan = None          # (key, VitPlan, keep-alive objects)
+        self._forced: Dict[int, torch.Tensor] = {}
+        self._trace_scores = False
+
+    # ------------------------------------------------------------------------------------------
+    def get_last_stats(self):
+        return self._last_stats
+
+    def get_last_trace(self) -> Dict[int, Dict[str, torch.Tensor]]:
+        """Per scheduled block: keep_idx [B,Np] int64, next_scores [B,Np] and (if enabled with
+        `trace_scores(True)`) the full scores [B,N] the stage ranked.  Test/diagnostic surface."""
+        if self._plan is None:
+            return {}
+        out = {}
+        for i, bufs in self._plan[3].items():
+            idx = self._forced.get(i, bufs["keep_idx"])
+            d = {"keep_idx": idx.long(), "next_scores": bufs["next_scores"]}
+            if bufs["scores"] is not None:
+                d["scores"] = bufs["scores"]
+            out[i] = d
+        return out
+
+    def trace_scores(self, on: bool = True):
+        self._trace_scores = bool(on)
+        self._plan = None
+        return self
+
+    def force_keep_idx(self, forced: Optional[Dict[int, torch.Tensor]]):
+        """Test hook for selection-conditional parity: use the given keep_idx
+        ([B, keep+1], CLS first, ascending) in the listed blocks instead of the device selection."""
+        self._forced = {}
+        for k, v in (forced or {}).items():
+            self._forced[int(k)] = v.to(torch.int32).contiguous()
+        self._plan = None
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def _describe(self):
+        m = self.m
+        pe = m.patch_embed.proj
+        if not isinstance(pe, nn.Conv2d) or pe.kernel_size != pe.stride or pe.kernel_size[0] != pe.kernel_size[1]:
+            raise NotImplementedError("RAJNIViTWrapper: patch_embed.proj must be a square Conv2d with stride == kernel")
+        pe_norm = getattr(m.patch_embed, "norm", None)
+        if pe_norm is not None and not isinstance(pe_norm, nn.Identity):
+            raise NotImplementedError("RAJNIViTWrapper: patch_embed.norm is not supported")
+        if not isinstance(m.head, nn.Linear):
+            raise NotImplementedError("RAJNIViTWrapper: base_model.head must be nn.Linear")
+        blk0 = self.blocks[0]
+        Cdim = m.cls_token.shape[-1]
+        heads = blk0.attn.num_heads
+        desc = dict(C=Cdim, H=heads, D=Cdim // heads, depth=len(self.blocks), hidden=blk0.mlp.fc1.out_features,
+                    num_classes=m.head.out_features, patch=pe.kernel_size[0], in_chans=pe.in_channels,
+                    ln_eps=float(blk0.norm1.eps), scale=float(blk0.attn.scale))
+        for i, blk in enumerate(self.blocks):
+            for ln in (blk.norm1, blk.norm2):
+                if not isinstance(ln, nn.LayerNorm) or ln.weight is None or float(ln.eps) != desc["ln_eps"]:
+                    raise NotImplementedError(f"block {i}: norm layers must be affine nn.LayerNorm with one eps")
+            act = getattr(blk.mlp, "act", None)
+            if not isinstance(act, nn.GELU) or getattr(act, "approximate", "none") != "none":
+                raise NotImplementedError(f"block {i}: mlp.act must be exact-erf nn.GELU (timm default)")
+            mlp_norm = getattr(blk.mlp, "norm", None)
+            if mlp_norm is not None and not isinstance(mlp_norm, nn.Identity):
+                raise NotImplementedError(f"block {i}: mlp.norm is not supported")
+            for extra in ("q_norm", "k_norm"):
+                mod = getattr(blk.attn, extra, None)
+                if mod is not None and not isinstance(mod, nn.Identity):
+                    raise NotImplementedError(f"block {i}: attn.{extra} is not supported (SURVEY Q5)")
+            if blk.attn.num_heads != heads or float(blk.attn.scale) != desc["scale"]:
+                raise NotImplementedError(f"block {i}: heads/scale differ between blocks")
+        if not isinstance(m.norm, nn.LayerNorm) or float(m.norm.eps) != desc["ln_eps"]:
+            raise NotImplementedError("RAJNIViTWrapper: base_model.norm must be nn.LayerNorm with the blocks' eps")
+        return desc
+
+    def _all_params(self):
+        return [p for p in self.m.parameters()]
+
+    def _pack_weights(self, device, dtype):
+        params = self._all_params()
+        key = (str(device), dtype) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._weights_key == key:
+            return self._weights
+        desc = self._describe()
+        m = self.m
+        pw = lambda w: ops.pack_weight(w, dtype, device)
+        pv = lambda v: ops.pack_vec(v, dtype, device)
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
+        W = dict(desc=desc)
+        W["patch_w"] = pw(m.patch_embed.proj.weight)
+        W["patch_b"] = pv(m.patch_embed.proj.bias) if m.patch_embed.proj.bias is not None else zeros(desc["C"])
+        W["cls"] = m.cls_token.detach().to(device=device, dtype=dtype).reshape(-1).contiguous()
+        W["pos"] = m.pos_embed.detach().to(device=device, dtype=dtype).reshape(-1, desc["C"]).contiguous()
+        W["norm_w"], W["norm_b"] = pv(m.norm.weight), pv(m.norm.bias)
+        W["head_w"] = pw(m.head.weight)
+        W["head_b"] = pv(m.head.bias) if m.head.bias is not None else zeros(desc["num_classes"])
+        blocks = []
+        for blk in self.blocks:
+            a = blk.attn
+            ls1 = getattr(blk, "ls1", None)
+            ls2 = getattr(blk, "ls2", None)
+            g1 = pv(ls1.gamma) if (ls1 is not None and hasattr(ls1, "gamma")) else None
+            g2 = pv(ls2.gamma) if (ls2 is not None and hasattr(ls2, "gamma")) else None
+            for ls, nm in ((ls1, "ls1"), (ls2, "ls2")):
+                if ls is not None and not isinstance(ls, nn.Identity) and not hasattr(ls, "gamma"):
+                    raise NotImplementedError(f"{nm} must be Identity or a LayerScale with .gamma")
+            for dp in (getattr(blk, "drop_path1", None), getattr(blk, "drop_path2", None)):
+                if dp is not None and not isinstance(dp, nn.Identity) and self.training:
+                    raise NotImplementedError("drop_path in training mode: this is the inference path")
+            blocks.append(dict(
+                norm1_w=pv(blk.norm1.weight), norm1_b=pv(blk.norm1.bias),
+                qkv_w=pw(a.qkv.weight), qkv_b=pv(a.qkv.bias) if a.qkv.bias is not None else zeros(3 * desc["C"]),
+                proj_w=pw(a.proj.weight), proj_b=pv(a.proj.bias) if a.proj.bias is not None else zeros(desc["C"]),
+                ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
+                fc1_w=pw(blk.mlp.fc1.weight), fc1_b=pv(blk.mlp.fc1.bias),
+                fc2_w=pw(blk.mlp.fc2.weight), fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
+        W["blocks"] = blocks
+        self._weights, self._weights_key = W, key
+        self._plan = None
+        return W
+
+    def _build_plan(self, B: int, S: int, device, dtype):
+        W = self._pack_weights(device, dtype)
+        d = W["desc"]
+        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores)
+        if self._plan is not None and self._plan[0] == key:
+            return self._plan
+        if S % d["patch"] != 0:
+            raise ValueError(f"image size {S} is not a multiple of the patch size {d['patch']}")
+        n0 = (S // d["patch"]) ** 2 + 1
+        pos_rows = W["pos"].shape[0]
+        if pos_rows >= n0:
+            pos_has_cls = 1      # reference: x + pos_embed[:, :N]  (model.py:37)
+        elif pos_rows == n0 - 1:
+            pos_has_cls = 0      # timm no_embed_class
+        else:
+            raise ValueError(f"pos_embed has {pos_rows} rows but the input yields {n0} tokens")
+        counts = plan_token_counts(n0, d["depth"], self.pruning_schedule)
+
+        blocks = (nat.Block * d["depth"])()
+        bufs: Dict[int, Dict[str, Optional[torch.Tensor]]] = {}
+        for i, bw in enumerate(W["blocks"]):
+            cb = blocks[i]
+            for name in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
+                         "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2"):
+                setattr(cb, name, nat.ptr(bw[name]))
+            if i in self.pruning_schedule:
+                cfg = self.pruning_schedule[i]
+                N = counts[i]
+                keep = ops.keep_count(cfg["keep_ratio"], N)
+                if keep > N - 1:
+                    raise ValueError(f"block {i}: keep_ratio {cfg['keep_ratio']} > 1 selects more tokens than exist")
+                kb = dict(keep_idx=torch.empty((B, keep + 1), dtype=torch.int32, device=device),
+                          next_scores=torch.empty((B, keep + 1), dtype=dtype, device=device),
+                          scores=torch.empty((B, N), dtype=dtype, device=device) if self._trace_scores else None)
+                bufs[i] = kb
+                cb.keep, cb.update = keep, int(cfg["update"])
+                cb.keep_idx, cb.next_scores, cb.scores = kb["keep_idx"].data_ptr(), kb["next_scores"].data_ptr(), \
+                    nat.ptr(kb["scores"])
+                if i in self._forced:
+                    f = self._forced[i].to(device)
+                    if tuple(f.shape) != (B, keep + 1):
+                        raise ValueError(f"forced keep_idx for block {i} has shape {tuple(f.shape)}, want {(B, keep + 1)}")
+                    self._forced[i] = f
+                    cb.forced_keep_idx = f.data_ptr()
+            else:
+                cb.keep = 0
+
+        plan = nat.VitPlan()
+        plan.dtype = nat.dtype_code(dtype)
+        plan.B, plan.in_chans, plan.img_size, plan.patch_size = B, d["in_chans"], S, d["patch"]
+        plan.C, plan.H, plan.D, plan.depth, plan.hidden = d["C"], d["H"], d["D"], d["depth"], d["hidden"]
+        plan.num_classes, plan.ln_eps, plan.attn_scale = d["num_classes"], d["ln_eps"], d["scale"]
+        plan.pos_has_cls = pos_has_cls
+        plan.patch_w, plan.patch_b = W["patch_w"].data_ptr(), W["patch_b"].data_ptr()
+        plan.cls_token, plan.pos_embed = W["cls"].data_ptr(), W["pos"].data_ptr()
+        plan.blocks = blocks
+        plan.norm_w, plan.norm_b = W["norm_w"].data_ptr(), W["norm_b"].data_ptr()
+        plan.head_w, plan.head_b = W["head_w"].data_ptr(), W["head_b"].data_ptr()
+        tc = (C.c_int32 * d["depth"])()
+        plan.token_counts = tc
+        plan.logits_ld = (d["num_classes"] + 7) // 8 * 8
+        nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes
+        self._plan = (key, plan, (blocks, tc, ws), bufs, counts)
+        return self._plan
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        nat.require_device(x, "input images")
+        if x.dim() != 4 or x.shape[-1] != x.shape[-2]:
+            raise ValueError(f"expected images [B, C, S, S], got {tuple(x.shape)}")
+        dtype = self.m.cls_token.dtype
+        if self.m.cls_token.device != x.device:
+            raise nat.NativeError(f"model is on {self.m.cls_token.device} but images are on {x.device}")
+        if x.dtype != dtype:
+            x = x.to(dtype)
+        x = x.contiguous()
+        B, S = x.shape[0], x.shape[-1]
+        _, plan, keep_alive, _, counts = self._build_plan(B, S, x.device, dtype)
+        ld = plan.logits_ld
+        logits = torch.empty((B, ld), dtype=dtype, device=x.device)
+        nat.check(nat.lib().rajni_vit_forward(C.byref(plan), x.data_ptr(), logits.data_ptr(),
+                                              nat.stream_ptr(x.device)), "rajni_vit_forward")
+        tc = keep_alive[1]
+        self._last_stats = {"token_counts": [int(tc[i]) for i in range(plan.depth)]}   # model.py:68
+        return logits[:, : plan.num_classes] if ld != plan.num_classes else logits

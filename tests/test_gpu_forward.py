@@ -1,0 +1,164 @@
+"""End-to-end parity of the HIP forward (RAJNIViTWrapper -> rajni_vit_forward) against the golden
+fixtures captured from the reference and against the CPU oracle.  GPU box only (`-m gpu`).
+
+Design follows SURVEY 4-3 (selection-conditional parity), because top-k on bf16 scores is not
+reproducible across implementations:
+  (a) get_last_stats() token counts: exact;
+  (b) with the REFERENCE's keep_idx injected, logits within 1e-2 of the logit scale (the bf16 budget
+      of BASELINE.json) of the reference's fp32 logits on the same bf16-representable weights/inputs;
+  (c) un-injected: the device's selection must be a valid top-k of the device's own scores (exact,
+      integer), its scores must match the reference's within bf16 rounding, and the logits must match
+      the ORACLE run with the device's selections injected.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import rajni_amd
+from oracle import rajni_oracle as orc
+from rajni_amd import timm_shaped as ts
+from helpers import load_case, case_state_dict, case_images, pruned_blocks
+
+DEV = "cuda"
+CASES = ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32"]
+
+
+def build(meta):
+    cfg = ts.CONFIGS[meta["cfg_name"]]
+    model = ts.create_model(cfg, seed=meta["seed"], std=meta["std"], bias_std=meta["bias_std"], round_bf16=True)
+    wrapped = rajni_amd.RAJNIViTWrapper(model, meta["schedule"]).to(DEV).to(torch.bfloat16).eval()
+    return cfg, wrapped
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_selection_conditional(name):
+    meta, data = load_case(name)
+    cfg, wrapped = build(meta)
+    images = torch.from_numpy(case_images(meta, data)).to(DEV)
+    forced = {i: torch.from_numpy(data[f"blk{i}.keep_idx"]).to(DEV) for i in pruned_blocks(meta)}
+    wrapped.force_keep_idx(forced)
+    logits = wrapped(images).float().cpu().numpy()
+    assert wrapped.get_last_stats()["token_counts"] == data["token_counts"].tolist()      # (a)
+    ref = data["logits"]
+    scale = np.abs(ref).max()
+    err = np.abs(logits - ref).max()
+    assert err <= 1e-2 * scale, f"{name}: max |dlogit| {err:.4g} vs scale {scale:.4g}"     # (b)
+    assert (logits.argmax(1) == ref.argmax(1)).all()
+    # carried scores of every stage (attention.py:58) match the reference's
+    tr = wrapped.get_last_trace()
+    for i in pruned_blocks(meta):
+        want = data[f"blk{i}.next_scores"]
+        got = tr[i]["next_scores"].float().cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_free_running(name):
+    meta, data = load_case(name)
+    cfg, wrapped = build(meta)
+    wrapped.trace_scores(True)
+    images_np = case_images(meta, data)
+    logits = wrapped(torch.from_numpy(images_np).to(DEV)).float().cpu().numpy()
+    assert wrapped.get_last_stats()["token_counts"] == data["token_counts"].tolist()
+    tr = wrapped.get_last_trace()
+    forced = {}
+    first = pruned_blocks(meta)[0]
+    for i in pruned_blocks(meta):
+        s = tr[i]["scores"].float().cpu().numpy().astype(np.float64)
+        idx = tr[i]["keep_idx"].cpu().numpy()
+        keep = idx.shape[1] - 1
+        # integer part: exactly the defined rule on the device's own scores
+        np.testing.assert_array_equal(idx, orc.select_tokens(s, keep))
+        forced[i] = idx
+        if i == first:
+            # before any selection differs the inputs are identical: scores match the reference
+            want = data[f"blk{i}.scores"]
+            assert np.abs(s - want).max() <= 2e-2 * np.abs(want).max()
+            agree = np.mean([len(set(a) & set(b)) / len(a) for a, b in zip(idx, data[f"blk{i}.keep_idx"])])
+            assert agree >= 0.93, f"{name}: stage-0 selection overlap {agree:.3f}"
+    # (c) logits vs the oracle with the device's selections injected
+    _, sd = case_state_dict(meta)
+    want, stats = orc.vit_forward(sd, images_np, meta["schedule"], depth=cfg.depth, num_heads=cfg.num_heads,
+                                  ln_eps=cfg.ln_eps, forced_keep=forced, dtype=np.float32)
+    scale = np.abs(want).max()
+    err = np.abs(logits - want).max()
+    assert err <= 1e-2 * scale, f"{name}: max |dlogit| {err:.4g} vs scale {scale:.4g}"
+    assert stats["token_counts"] == wrapped.get_last_stats()["token_counts"]
+
+
+def test_keep_ratio_one_and_empty_schedule_equal_base():
+    """keep_ratio=1.0 and an empty schedule are the unpruned network."""
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]
+    imgs = torch.from_numpy(ts.bf16_round_np(np.random.default_rng(0).standard_normal((3, 3, 64, 64), dtype=np.float32))).to(DEV)
+    outs = []
+    for sched in ({}, {1: {"keep_ratio": 1.0}, 2: {"keep_ratio": 1.0, "update": False}}):
+        m = ts.create_model(cfg, seed=5, std=0.08, bias_std=0.02, round_bf16=True)
+        w = rajni_amd.RAJNIViTWrapper(m, sched).to(DEV).to(torch.bfloat16)
+        outs.append(w(imgs).float().cpu())
+        assert w.get_last_stats()["token_counts"] == [17] * 4
+    assert torch.equal(outs[0], outs[1])
+    base = ts.create_model(cfg, seed=5, std=0.08, bias_std=0.02, round_bf16=True).to(DEV).to(torch.bfloat16)
+    ref = base(imgs.to(torch.bfloat16)).float().cpu()
+    assert (outs[0] - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_string_keys_and_update_chain():
+    """B1 fix: JSON-style string keys prune; Q3: update=False re-uses carried scores."""
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]
+    imgs = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 3, 64, 64), dtype=np.float32)).to(DEV)
+    sched_int = {1: {"keep_ratio": 0.75}, 2: {"keep_ratio": 0.6, "update": False}}
+    sched_str = {"1": {"keep_ratio": 0.75}, "2": {"keep_ratio": 0.6, "update": False}}
+    res = []
+    for s in (sched_int, sched_str):
+        w = rajni_amd.RAJNIViTWrapper(ts.create_model(cfg, seed=2, std=0.08), s).to(DEV).to(torch.bfloat16)
+        res.append(w(imgs))
+        assert w.get_last_stats()["token_counts"] == [17, 17, 13, 8]
+        tr = w.get_last_trace()
+        # block 2 ranks the scores carried from block 1: its kept scores are a subset of block 1's
+        a = tr[1]["next_scores"].float().cpu().numpy()
+        b = tr[2]["next_scores"].float().cpu().numpy()
+        i2 = tr[2]["keep_idx"].cpu().numpy()
+        np.testing.assert_array_equal(b, np.take_along_axis(a, i2, axis=1))
+    assert torch.equal(res[0], res[1])
+
+
+def test_module_level_api_matches_oracle():
+    """RAJNIAttention.forward / compute_importance used stand-alone (reference attention.py:17-60)."""
+    from rajni_amd.wrapper import RAJNIAttention, compute_importance
+    cfg = ts.CONFIGS["vit_tiny_patch16_224"]
+    model = ts.create_model(cfg, seed=3, std=0.06, bias_std=0.02, round_bf16=True)
+    sd = ts.state_dict_numpy(model)
+    att = RAJNIAttention(model.blocks[0].attn, keep_ratio=0.7, update=True).to(DEV).to(torch.bfloat16)
+    x = ts.bf16_round_np(np.random.default_rng(4).standard_normal((2, 197, 192), dtype=np.float32))
+    out, keep_idx, nxt = att(torch.from_numpy(x).to(DEV).to(torch.bfloat16))
+    assert keep_idx.dtype == torch.int64 and tuple(keep_idx.shape) == (2, 138) and tuple(out.shape) == (2, 138, 192)
+    assert (keep_idx[:, 0] == 0).all() and (keep_idx[:, 1:].diff(dim=1) > 0).all()
+    want_out, _, want_nxt, _ = orc.rajni_attention(x, sd, "blocks.0.attn.", 3, 0.7, True, None,
+                                                   forced_keep_idx=keep_idx.cpu().numpy())
+    assert np.abs(out.float().cpu().numpy() - want_out).max() <= 1.5e-2 * np.abs(want_out).max()
+    assert np.abs(nxt.float().cpu().numpy() - want_nxt).max() <= 1e-2 * np.abs(want_nxt).max()
+    # prev_scores + update=False: pure selection of the given scores
+    att2 = RAJNIAttention(model.blocks[1].attn, keep_ratio=0.5, update=False).to(DEV).to(torch.bfloat16)
+    prev = torch.rand(2, 197, device=DEV).to(torch.bfloat16)
+    _, ki, _ = att2(torch.from_numpy(x).to(DEV).to(torch.bfloat16), prev)
+    np.testing.assert_array_equal(ki.cpu().numpy(), orc.select_tokens(prev.float().cpu().numpy(), 98))
+    qkv = torch.randn(2, 50, 3 * 128, device=DEV).to(torch.bfloat16)
+    sc = compute_importance(qkv, 2)
+    assert sc.dtype == torch.bfloat16 and tuple(sc.shape) == (2, 50)
+    want = orc.importance_scores(qkv.float().cpu().numpy(), 2)
+    assert np.abs(sc.float().cpu().numpy() - want).max() <= 6e-3 * want.max()
+
+
+def test_evaluate_model_on_device():
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]
+    w = rajni_amd.RAJNIViTWrapper(ts.create_model(cfg, seed=0, std=0.08), {1: {"keep_ratio": 0.5}}).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    loader = [(torch.randn(8, 3, 64, 64, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(3)]
+    acc, thr = rajni_amd.evaluate_model(w, loader, device="cuda", max_batches=2, warmup=4)
+    assert 0.0 <= acc <= 100.0 and thr > 0
+    # accuracy is exactly argmax agreement of the model's own logits
+    w.to(DEV)
+    correct = sum(int((w(x.to(DEV)).argmax(1).cpu() == y).sum()) for x, y in loader[:2])
+    assert acc == pytest.approx(100.0 * correct / 16)
