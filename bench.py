@@ -47,10 +47,30 @@ def flops_per_image(cfg, schedule):
     return total, counts
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs but grants one GPU's share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, schedule, seconds_budget=20.0):
     """Oracle (numpy port of the reference algorithm) on the host cores, fp32, same model/schedule."""
     from oracle import rajni_oracle as orc
     from rajni_amd import timm_shaped as ts
+    cores = usable_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
     sd = ts.synth_state_dict(cfg, seed=0)
     rng = np.random.default_rng(1234)
     bsz = 8
@@ -65,9 +85,11 @@ def cpu_baseline(cfg, schedule, seconds_budget=20.0):
         dt = time.time() - t0
         if dt > seconds_budget or n >= 256:
             break
-    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+    del limiter
+    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} synthetic 3x{cfg.img_size}x{cfg.img_size} images in batches of {bsz}, "
-                      f"same model dims and README schedule, fp32 numpy oracle (OpenBLAS threads = all cores), {dt:.1f} s"}
+                      f"same model dims and README schedule, fp32 numpy oracle, BLAS threads = {cores} "
+                      f"(usable cores of {os.cpu_count()} logical), {dt:.1f} s"}
 
 
 def main():

@@ -83,9 +83,10 @@ int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, 
 
 /* ---- LayerNorm over the last axis (blk.norm1 / norm2 / m.norm)            model.py:51,59,65 ----
  * x rows are `x_row_stride` elements apart (lets the final norm read CLS rows only), y is dense
- * [rows, C].  w,b are fp32 [C]. C % 8 == 0. */
+ * [rows, C] in `dtype`.  x is `dtype`, or fp32 when x_f32 != 0 (the fp32 residual stream).
+ * w,b are fp32 [C]. C % 8 == 0. */
 int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,
-                    int rows, int C, float eps, int dtype, rajni_stream_t stream);
+                    int rows, int C, float eps, int dtype, int x_f32, rajni_stream_t stream);
 
 /* ---- linear layers with fused epilogues (a3, a9, a13, a15) ----
  * y[M,N] = epi(x[M,K] W[N,K]^T).  W must be allocated with its row count padded up to a multiple
@@ -104,16 +105,17 @@ typedef struct {
   int M, N, K;
   int epilogue;
   int dtype;
+  int stream_f32;  /* RESID only: resid and y are the fp32 residual stream (1) instead of `dtype` (0) */
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
 
 /* ---- a12: patch-embed + CLS + pos-embed                                    model.py:34-37 ----
  * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad128), Cin*P*P] (k order c,ky,kx),
  * bias fp32 [C]; cls [C]; pos [(1 or 0)+(S/P)^2, C] (`pos_has_cls`=0 is timm no_embed_class:
- * SURVEY B3).  The im2col is fused into the GEMM's tile loads.  P % 8 == 0, S % P == 0. */
+ * SURVEY B3); x is written as fp32 when x_f32 != 0.  The im2col is fused into the GEMM's tile loads.  P % 8 == 0, S % P == 0. */
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
-                      const void* pos, int pos_has_cls, void* x, int B, int Cin, int S, int P,
-                      int C, int dtype, rajni_stream_t stream);
+                      const void* pos, int pos_has_cls, void* x, int x_f32, int B, int Cin, int S,
+                      int P, int C, int dtype, rajni_stream_t stream);
 
 /* ---- a11-a16: the whole RAJNIViTWrapper.forward                            model.py:30-69 ---- */
 typedef struct {
@@ -147,6 +149,9 @@ typedef struct {
   void* workspace; size_t workspace_bytes;     /* >= rajni_vit_workspace_bytes() */
   int32_t* token_counts;                       /* HOST int32[depth] out: tokens at block entry (model.py:43) */
   int logits_ld;                               /* row stride of `logits` in elements (0 = num_classes); % 8 == 0 */
+  int resid_bf16;                              /* 0 (default): the residual stream x is kept in fp32 between
+                                                  blocks (2x closer to the fp32 reference than a bf16 stream, see
+                                                  DESIGN.md); 1: keep it in bf16 like the reference's bf16 model */
 } rajni_vit_plan;
 
 size_t rajni_vit_workspace_bytes(const rajni_vit_plan* plan);

@@ -40,14 +40,14 @@ ProfScope::ProfScope(int kclass, hipStream_t stream, double flops, double bytes)
   if (!(g_prof_mask & (1u << kclass))) return;
   ProfRec r{kclass, get_event(), get_event(), flops, bytes};
   if (!r.e0 || !r.e1) return;
-  hipEventRecord(r.e0, s);
+  (void)hipEventRecord(r.e0, s);
   g_pending.push_back(r);
   rec = reinterpret_cast<void*>(g_pending.size());  // index + 1
 }
 ProfScope::~ProfScope() {
   if (!rec) return;
   const size_t i = reinterpret_cast<size_t>(rec) - 1;
-  hipEventRecord(g_pending[i].e1, s);
+  (void)hipEventRecord(g_pending[i].e1, s);
 }
 
 extern "C" {
@@ -63,7 +63,7 @@ int rajni_device_check(void) {
     return RAJNI_ERR_LAUNCH;
   }
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, dev);
   if (e != hipSuccess) {
@@ -121,9 +121,9 @@ int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, 
 }
 
 int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,
-                    int rows, int C, float eps, int dtype, rajni_stream_t stream) {
+                    int rows, int C, float eps, int dtype, int x_f32, rajni_stream_t stream) {
   NEED_BF16("rajni_layernorm");
-  return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, (hipStream_t)stream);
+  return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, x_f32, (hipStream_t)stream);
 }
 
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {
@@ -132,10 +132,10 @@ int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {
 }
 
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
-                      const void* pos, int pos_has_cls, void* x, int B, int Cin, int S, int P,
-                      int C, int dtype, rajni_stream_t stream) {
+                      const void* pos, int pos_has_cls, void* x, int x_f32, int B, int Cin, int S,
+                      int P, int C, int dtype, rajni_stream_t stream) {
   NEED_BF16("rajni_patch_embed");
-  return launch_patch_embed(images, w, bias, cls, pos, pos_has_cls, x, B, Cin, S, P, C,
+  return launch_patch_embed(images, w, bias, cls, pos, pos_has_cls, x, x_f32, B, Cin, S, P, C,
                             (hipStream_t)stream);
 }
 
@@ -144,7 +144,7 @@ const char* rajni_profile_class_name(int k) {
   return (k >= 0 && k < RAJNI_NUM_KCLASS) ? kNames[k] : "";
 }
 void rajni_profile_reset(void) {
-  for (auto& r : g_pending) { hipEventSynchronize(r.e1); g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+  for (auto& r : g_pending) { (void)hipEventSynchronize(r.e1); g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
   g_pending.clear();
   for (int i = 0; i < RAJNI_NUM_KCLASS; ++i) { g_launches[i] = 0; g_ms[i] = g_flops[i] = g_bytes[i] = 0.0; }
 }

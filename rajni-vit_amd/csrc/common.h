@@ -85,10 +85,10 @@ struct ProfScope {
 // internal launchers shared between the per-op ABI and the whole-forward plan
 int launch_linear(const rajni_linear_args& a, hipStream_t s);
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
-                       const void* pos, int pos_has_cls, void* x, int B, int Cin, int S, int P,
-                       int C, hipStream_t s);
+                       const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
+                       int P, int C, hipStream_t s);
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
-                     int C, float eps, hipStream_t s);
+                     int C, float eps, int x_f32, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, hipStream_t s);
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,

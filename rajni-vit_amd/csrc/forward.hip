@@ -19,11 +19,11 @@ struct Workspace {
 
 Workspace carve(const rajni_vit_plan& p) {
   const size_t gw = p.img_size / p.patch_size, n0 = gw * gw + 1;
-  const size_t rows = (size_t)p.B * n0, es = 2;
+  const size_t rows = (size_t)p.B * n0, es = 2, xs = p.resid_bf16 ? 2 : 4;
   Workspace w{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-  const size_t oxa = take(rows * p.C * es), oxb = take(rows * p.C * es), oxn = take(rows * p.C * es);
+  const size_t oxa = take(rows * p.C * xs), oxb = take(rows * p.C * xs), oxn = take(rows * p.C * es);
   const size_t oqkv = take(rows * 3 * p.C * es), oatt = take(rows * p.C * es);
   const size_t ohid = take(rows * p.hidden * es), ocls = take((size_t)p.B * p.C * es);
   const size_t oscf = take(rows * es);
@@ -77,8 +77,9 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
   const int gw = p.img_size / p.patch_size;
   int N = gw * gw + 1;
 
+  const int sf32 = p.resid_bf16 ? 0 : 1;  // residual stream element type
   rc = launch_patch_embed(images, p.patch_w, p.patch_b, p.cls_token, p.pos_embed, p.pos_has_cls,
-                          w.xa, B, p.in_chans, p.img_size, p.patch_size, C, s);
+                          w.xa, sf32, B, p.in_chans, p.img_size, p.patch_size, C, s);
   if (rc != RAJNI_OK) return rc;
 
   char* cur = w.xa;
@@ -90,7 +91,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (p.token_counts) p.token_counts[i] = N;  // model.py:43
     const int M = B * N;
     // ---- norm1 + qkv on ALL N tokens (model.py:51, attention.py:21-22)
-    rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, s);
+    rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, s);
     if (rc != RAJNI_OK) return rc;
     rajni_linear_args g{};
     g.dtype = RAJNI_BF16;
@@ -143,7 +144,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     g = rajni_linear_args{};
     g.dtype = RAJNI_BF16;
     g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1;
-    g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID;
+    g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     if (idx) {
       g.r_idx = idx; g.r_np = Np; g.r_nsrc = N;
       g.y = oth; g.ldc = C;
@@ -157,7 +158,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     N = Np;
 
     // ---- MLP (model.py:59): norm2 -> fc1 + GELU -> fc2 + LayerScale + residual (in place)
-    rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, s);
+    rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
     g.dtype = RAJNI_BF16;
@@ -169,13 +170,13 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     g.dtype = RAJNI_BF16;
     g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2;
     g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = Mp; g.N = C; g.K = p.hidden;
-    g.epilogue = RAJNI_EPI_BIAS_RESID;
+    g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
   }
 
   // ---- final norm on the CLS rows only (LN is per token; model.py:65-66) + head
-  rc = launch_layernorm(cur, (long)N * C, p.norm_w, p.norm_b, w.clsn, B, C, p.ln_eps, s);
+  rc = launch_layernorm(cur, (long)N * C, p.norm_w, p.norm_b, w.clsn, B, C, p.ln_eps, sf32, s);
   if (rc != RAJNI_OK) return rc;
   rajni_linear_args g{};
   g.dtype = RAJNI_BF16;

@@ -31,9 +31,9 @@ struct GemmParams {
   const bf16_t* W; long ldw;
   const float* bias;
   const float* gamma;
-  const bf16_t* R; long ldr;
+  const void* R; long ldr;      // residual stream rows (bf16 or fp32, see SF32)
   const int* ridx; int r_np, r_nsrc;
-  bf16_t* Y; long ldc;
+  void* Y; long ldc;            // output (fp32 when SF32: RESID / PATCH write the residual stream)
   int M, N, K;
   int tiles_n, total_tiles;
   // patch-embed A loader / epilogue
@@ -61,7 +61,43 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-template <int EPI, int ALOAD>
+// load / store 16 consecutive stream elements (bf16 or fp32) as floats
+template <bool F32>
+__device__ __forceinline__ void load16(const void* base, long off, float* f) {
+  if (F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 t = q[i]; f[4*i] = t.x; f[4*i+1] = t.y; f[4*i+2] = t.z; f[4*i+3] = t.w; }
+  } else {
+    const bf16_t* q = reinterpret_cast<const bf16_t*>(base) + off;
+    unpack8(*reinterpret_cast<const uint4*>(q), f);
+    unpack8(*reinterpret_cast<const uint4*>(q + 8), f + 8);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ float load1(const void* base, long off) {
+  return F32 ? reinterpret_cast<const float*>(base)[off] : bf2f(reinterpret_cast<const bf16_t*>(base)[off]);
+}
+template <bool F32>
+__device__ __forceinline__ void store16(void* base, long off, const float* v) {
+  if (F32) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = make_float4(v[4*i], v[4*i+1], v[4*i+2], v[4*i+3]);
+  } else {
+    bf16_t* q = reinterpret_cast<bf16_t*>(base) + off;
+    *reinterpret_cast<uint4*>(q) = pack8(v);
+    *reinterpret_cast<uint4*>(q + 8) = pack8(v + 8);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void store1(void* base, long off, float v) {
+  if (F32) reinterpret_cast<float*>(base)[off] = v;
+  else reinterpret_cast<bf16_t*>(base)[off] = f2bf(v);
+}
+
+// SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32
+template <int EPI, int ALOAD, bool SF32>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -192,17 +228,16 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
         const int b = m / p.r_np;
         rrow = (long)b * p.r_nsrc + p.ridx[m];
       }
-      const bf16_t* rp = p.R + rrow * p.ldr + nb;
+      const long roff = rrow * p.ldr + nb;
       if (nb + 16 <= p.N) {
         float rf[16];
-        unpack8(*reinterpret_cast<const uint4*>(rp), rf);
-        unpack8(*reinterpret_cast<const uint4*>(rp + 8), rf + 8);
+        load16<SF32>(p.R, roff, rf);
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = fmaf(gam[j], v[j], rf[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], bf2f(rp[j]));
+          if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], load1<SF32>(p.R, roff + j));
       }
     } else if (EPI == EPI_PATCH) {
       const int b = m / p.npatch, pp = m - b * p.npatch;
@@ -220,34 +255,34 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
           if (nb + j < p.N) v[j] += bf2f(pr[j]);
       }
     }
-    bf16_t* yp = p.Y + orow * p.ldc + nb;
+    const long yoff = orow * p.ldc + nb;
     if (nb + 16 <= p.N) {
-      *reinterpret_cast<uint4*>(yp) = pack8(v);
-      *reinterpret_cast<uint4*>(yp + 8) = pack8(v + 8);
+      store16<SF32>(p.Y, yoff, v);
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j)
-        if (nb + j < p.N) yp[j] = f2bf(v[j]);
+        if (nb + j < p.N) store1<SF32>(p.Y, yoff + j, v[j]);
     }
   }
 }
 
 // x[b,0,:] = cls + pos[0]  (or cls alone when pos has no CLS row)
-__global__ void cls_pos_kernel(const bf16_t* cls, const bf16_t* pos, int pos_has_cls, bf16_t* x,
+template <bool SF32>
+__global__ void cls_pos_kernel(const bf16_t* cls, const bf16_t* pos, int pos_has_cls, void* x,
                                long img_stride, int B, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i - b * C;
   float v = bf2f(cls[c]);
   if (pos_has_cls) v += bf2f(pos[c]);
-  x[(long)b * img_stride + c] = f2bf(v);
+  store1<SF32>(x, (long)b * img_stride + c, v);
 }
 
-template <int EPI, int ALOAD>
+template <int EPI, int ALOAD, bool SF32>
 int launch_gemm(const GemmParams& p, int kclass, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tn<EPI, ALOAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tn<EPI, ALOAD, SF32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     if (e != hipSuccess) {
       rajni_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
@@ -257,7 +292,7 @@ int launch_gemm(const GemmParams& p, int kclass, hipStream_t s) {
   }
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
                  2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
-  hipLaunchKernelGGL((gemm_bf16_tn<EPI, ALOAD>), dim3(p.total_tiles), dim3(256), GEMM_LDS, s, p);
+  hipLaunchKernelGGL((gemm_bf16_tn<EPI, ALOAD, SF32>), dim3(p.total_tiles), dim3(256), GEMM_LDS, s, p);
   RAJNI_CHECK_LAUNCH("gemm_bf16_tn");
   return RAJNI_OK;
 }
@@ -277,19 +312,20 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   p.X = (const bf16_t*)a.x; p.lda = a.lda;
   p.W = (const bf16_t*)a.w; p.ldw = a.ldw;
   p.bias = a.bias; p.gamma = a.gamma;
-  p.R = (const bf16_t*)a.resid; p.ldr = a.ldr;
+  p.R = a.resid; p.ldr = a.ldr;
   p.ridx = a.r_idx; p.r_np = a.r_np > 0 ? a.r_np : 1; p.r_nsrc = a.r_nsrc;
-  p.Y = (bf16_t*)a.y; p.ldc = a.ldc;
+  p.Y = a.y; p.ldc = a.ldc;
   p.M = a.M; p.N = a.N; p.K = a.K;
   p.tiles_n = (a.N + BN - 1) / BN;
   p.total_tiles = p.tiles_n * ((a.M + BM - 1) / BM);
   switch (a.epilogue) {
-    case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN>(p, KC_GEMM_BIAS, s);
-    case RAJNI_EPI_BIAS_GELU: return launch_gemm<EPI_GELU, ALOAD_PLAIN>(p, KC_GEMM_GELU, s);
+    case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN, false>(p, KC_GEMM_BIAS, s);
+    case RAJNI_EPI_BIAS_GELU: return launch_gemm<EPI_GELU, ALOAD_PLAIN, false>(p, KC_GEMM_GELU, s);
     case RAJNI_EPI_BIAS_RESID:
       RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0, RAJNI_ERR_INVALID,
                     "rajni_linear: RESID epilogue needs resid and ldr %% 8 == 0");
-      return launch_gemm<EPI_RESID, ALOAD_PLAIN>(p, KC_GEMM_RESID, s);
+      return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true>(p, KC_GEMM_RESID, s)
+                          : launch_gemm<EPI_RESID, ALOAD_PLAIN, false>(p, KC_GEMM_RESID, s);
     default:
       rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
       return RAJNI_ERR_INVALID;
@@ -297,8 +333,8 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
 }
 
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
-                       const void* pos, int pos_has_cls, void* x, int B, int Cin, int S, int P,
-                       int C, hipStream_t s) {
+                       const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
+                       int P, int C, hipStream_t s) {
   RAJNI_REQUIRE(images && w && cls && pos && x, RAJNI_ERR_INVALID, "rajni_patch_embed: null pointer");
   RAJNI_REQUIRE(P >= 8 && (P & (P - 1)) == 0 && S % P == 0 && S % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_patch_embed: patch size must be a power of two >= 8 dividing the image (P=%d S=%d)", P, S);
@@ -312,19 +348,24 @@ int launch_patch_embed(const void* images, const void* w, const float* bias, con
   p.X = (const bf16_t*)images; p.lda = 0;
   p.W = (const bf16_t*)w; p.ldw = K;
   p.bias = bias;
-  p.Y = (bf16_t*)x; p.ldc = C;
+  p.Y = x; p.ldc = C;
   p.M = B * npatch; p.N = C; p.K = K;
   p.tiles_n = (C + BN - 1) / BN;
   p.total_tiles = p.tiles_n * ((p.M + BM - 1) / BM);
   p.cin = Cin; p.S = S; p.log2ps = log2ps; p.gw = gw; p.npatch = npatch;
   p.pos = (const bf16_t*)pos; p.pos_off = pos_has_cls ? 1 : 0;
-  int rc = launch_gemm<EPI_PATCH, ALOAD_PATCH>(p, KC_GEMM_PATCH, s);
+  int rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)
+                   : launch_gemm<EPI_PATCH, ALOAD_PATCH, false>(p, KC_GEMM_PATCH, s);
   if (rc != RAJNI_OK) return rc;
   {
     ProfScope prof(KC_CLS_POS, s, 0.0, 6.0 * B * C);
     const int n = B * C;
-    hipLaunchKernelGGL(cls_pos_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)cls,
-                       (const bf16_t*)pos, pos_has_cls, (bf16_t*)x, (long)(npatch + 1) * C, B, C);
+    if (out_f32)
+      hipLaunchKernelGGL(cls_pos_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)cls,
+                         (const bf16_t*)pos, pos_has_cls, x, (long)(npatch + 1) * C, B, C);
+    else
+      hipLaunchKernelGGL(cls_pos_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)cls,
+                         (const bf16_t*)pos, pos_has_cls, x, (long)(npatch + 1) * C, B, C);
     RAJNI_CHECK_LAUNCH("cls_pos_kernel");
   }
   return RAJNI_OK;

@@ -6,7 +6,8 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 4;  // 16-byte chunks per lane: C <= 64*8*4 = 2048
 
-__global__ void __launch_bounds__(256) layernorm_bf16(const bf16_t* __restrict__ x, long xs,
+template <bool XF32>
+__global__ void __launch_bounds__(256) layernorm_bf16(const void* __restrict__ xv, long xs,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ b,
                                                       bf16_t* __restrict__ y, int rows, int C,
@@ -15,14 +16,20 @@ __global__ void __launch_bounds__(256) layernorm_bf16(const bf16_t* __restrict__
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const int nchunk = C >> 3;
-  const bf16_t* xr = x + (long)row * xs;
   float v[LN_MAX_CHUNKS][8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
-      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
+      if (XF32) {
+        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xv) + (long)row * xs + c * 8);
+        const float4 a = q[0], d = q[1];
+        v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+        v[i][4] = d.x; v[i][5] = d.y; v[i][6] = d.z; v[i][7] = d.w;
+      } else {
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(xv) + (long)row * xs + c * 8), v[i]);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) sum += v[i][j];
     }
@@ -79,13 +86,17 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const uint4* __restric
 }  // namespace
 
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
-                     int C, float eps, hipStream_t s) {
+                     int C, float eps, int x_f32, hipStream_t s) {
   RAJNI_REQUIRE(x && w && b && y, RAJNI_ERR_INVALID, "rajni_layernorm: null pointer");
   RAJNI_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS && xs % 8 == 0,
                 RAJNI_ERR_UNSUPPORTED, "rajni_layernorm: need C %% 8 == 0, C <= 2048, stride %% 8 == 0 (C=%d)", C);
-  ProfScope prof(KC_LAYERNORM, s, 8.0 * rows * C, 4.0 * rows * C);
-  hipLaunchKernelGGL(layernorm_bf16, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, xs, w,
-                     b, (bf16_t*)y, rows, C, eps);
+  ProfScope prof(KC_LAYERNORM, s, 8.0 * rows * C, (x_f32 ? 6.0 : 4.0) * rows * C);
+  if (x_f32)
+    hipLaunchKernelGGL(layernorm_bf16<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, w, b,
+                       (bf16_t*)y, rows, C, eps);
+  else
+    hipLaunchKernelGGL(layernorm_bf16<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, w, b,
+                       (bf16_t*)y, rows, C, eps);
   RAJNI_CHECK_LAUNCH("layernorm_bf16");
   return RAJNI_OK;
 }

@@ -30,7 +30,7 @@ class LinearArgs(C.Structure):
                 ("bias", c_void_p), ("gamma", c_void_p), ("resid", c_void_p), ("ldr", c_long),
                 ("r_idx", c_void_p), ("r_np", c_int), ("r_nsrc", c_int),
                 ("y", c_void_p), ("ldc", c_long), ("M", c_int), ("N", c_int), ("K", c_int),
-                ("epilogue", c_int), ("dtype", c_int)]
+                ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int)]
 
 
 class Block(C.Structure):
@@ -54,7 +54,7 @@ class VitPlan(C.Structure):
                 ("pos_embed", c_void_p), ("blocks", C.POINTER(Block)),
                 ("norm_w", c_void_p), ("norm_b", c_void_p), ("head_w", c_void_p), ("head_b", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-                ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int)]
+                ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int), ("resid_bf16", c_int)]
 
 
 _SIGS = {
@@ -69,9 +69,9 @@ _SIGS = {
     "rajni_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_int, c_void_p]),
     "rajni_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
-                                c_int, c_void_p]),
+                                c_int, c_int, c_void_p]),
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
-    "rajni_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+    "rajni_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rajni_vit_workspace_bytes": (c_size_t, [C.POINTER(VitPlan)]),
     "rajni_vit_forward": (c_int, [C.POINTER(VitPlan), c_void_p, c_void_p, c_void_p]),

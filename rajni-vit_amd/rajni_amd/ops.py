@@ -108,19 +108,22 @@ def attention(qkv: torch.Tensor, keep_idx: Optional[torch.Tensor], num_heads: in
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, rows: Optional[int] = None,
-              row_stride: Optional[int] = None) -> torch.Tensor:
-    """LayerNorm over the last axis; w, b fp32.  With rows/row_stride reads a strided subset of rows."""
+              row_stride: Optional[int] = None, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """LayerNorm over the last axis; w, b fp32.  x may be `out_dtype` or fp32 (the fp32 residual
+    stream); the result is `out_dtype`.  With rows/row_stride reads a strided subset of rows."""
     nat.require_device(x, "x")
     x = x.contiguous()
+    x_f32 = int(x.dtype == torch.float32 and out_dtype != torch.float32)
     Cc = x.shape[-1]
     if rows is None:
         rows = x.numel() // Cc
         row_stride = Cc
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     else:
-        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
     nat.check(nat.lib().rajni_layernorm(x.data_ptr(), row_stride, w.data_ptr(), b.data_ptr(), out.data_ptr(), rows,
-                                        Cc, float(eps), _dt(x), nat.stream_ptr(x.device)), "rajni_layernorm")
+                                        Cc, float(eps), nat.dtype_code(out_dtype), x_f32,
+                                        nat.stream_ptr(x.device)), "rajni_layernorm")
     return out
 
 
@@ -129,19 +132,21 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
            resid: Optional[torch.Tensor] = None, r_idx: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x @ W^T): x [..., K]; w_packed from pack_weight(); bias/gamma fp32 [n_out].
-    resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID."""
+    resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID; an fp32
+    resid selects the fp32 residual stream (the output is then fp32 too)."""
     nat.require_device(x, "x")
     x = x.contiguous()
     K = x.shape[-1]
     M = x.numel() // K
     ld = (n_out + 7) // 8 * 8
+    stream_f32 = int(resid is not None and resid.dtype == torch.float32 and x.dtype != torch.float32)
     if out is None:
-        out = torch.empty((M, ld), dtype=x.dtype, device=x.device)
+        out = torch.empty((M, ld), dtype=torch.float32 if stream_f32 else x.dtype, device=x.device)
     a = nat.LinearArgs()
     a.x, a.lda, a.w, a.ldw = x.data_ptr(), K, w_packed.data_ptr(), w_packed.shape[1]
     a.bias, a.gamma = nat.ptr(bias), nat.ptr(gamma)
     a.y, a.ldc = out.data_ptr(), out.shape[-1] if out.dim() == 2 else out.stride(-2)
-    a.M, a.N, a.K, a.epilogue, a.dtype = M, n_out, K, epilogue, _dt(x)
+    a.M, a.N, a.K, a.epilogue, a.dtype, a.stream_f32 = M, n_out, K, epilogue, _dt(x), stream_f32
     if resid is not None:
         resid = resid.contiguous()
         a.resid, a.ldr = resid.data_ptr(), resid.shape[-1]
@@ -154,14 +159,15 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
 
 
 def patch_embed(images: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cls: torch.Tensor,
-                pos: torch.Tensor, pos_has_cls: bool, patch: int, embed_dim: int) -> torch.Tensor:
+                pos: torch.Tensor, pos_has_cls: bool, patch: int, embed_dim: int,
+                out_f32: bool = False) -> torch.Tensor:
     nat.require_device(images, "images")
     images = images.contiguous()
     B, Cin, S, _ = images.shape
     n = (S // patch) ** 2 + 1
-    x = torch.empty((B, n, embed_dim), dtype=images.dtype, device=images.device)
+    x = torch.empty((B, n, embed_dim), dtype=torch.float32 if out_f32 else images.dtype, device=images.device)
     nat.check(nat.lib().rajni_patch_embed(images.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), cls.data_ptr(),
-                                          pos.data_ptr(), int(pos_has_cls), x.data_ptr(), B, Cin, S, patch,
+                                          pos.data_ptr(), int(pos_has_cls), x.data_ptr(), int(out_f32), B, Cin, S, patch,
                                           embed_dim, _dt(images), nat.stream_ptr(images.device)),
               "rajni_patch_embed")
     return x

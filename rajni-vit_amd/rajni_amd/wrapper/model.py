@@ -67,6 +67,9 @@ class RAJNIViTWrapper(nn.Module):
         self._plan = None          # (key, VitPlan, keep-alive objects)
         self._forced: Dict[int, torch.Tensor] = {}
         self._trace_scores = False
+        # residual stream precision between blocks: fp32 (default; see DESIGN.md "numerics") or the
+        # model dtype like the reference's bf16 model (`set_residual_dtype(torch.bfloat16)`)
+        self._resid_bf16 = False
 
     # ------------------------------------------------------------------------------------------
     def get_last_stats(self):
@@ -81,10 +84,23 @@ class RAJNIViTWrapper(nn.Module):
         for i, bufs in self._plan[3].items():
             idx = self._forced.get(i, bufs["keep_idx"])
             d = {"keep_idx": idx.long(), "next_scores": bufs["next_scores"]}
-            if bufs["scores"] is not None:
+            # a stage ranks freshly computed scores iff `update` or nothing was carried into it
+            # (attention.py:25); otherwise it ranked the previous stage's next_scores
+            sched = self.pruning_schedule
+            recomputed = sched[i]["update"] or (i - 1) not in sched
+            if bufs["scores"] is not None and recomputed:
                 d["scores"] = bufs["scores"]
+            elif not recomputed:
+                d["scores"] = self._plan[3][i - 1]["next_scores"]
             out[i] = d
         return out
+
+    def set_residual_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("residual stream dtype must be torch.float32 or torch.bfloat16")
+        self._resid_bf16 = dtype == torch.bfloat16
+        self._plan = None
+        return self
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
@@ -186,7 +202,7 @@ class RAJNIViTWrapper(nn.Module):
     def _build_plan(self, B: int, S: int, device, dtype):
         W = self._pack_weights(device, dtype)
         d = W["desc"]
-        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores)
+        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16)
         if self._plan is not None and self._plan[0] == key:
             return self._plan
         if S % d["patch"] != 0:
@@ -244,6 +260,7 @@ class RAJNIViTWrapper(nn.Module):
         tc = (C.c_int32 * d["depth"])()
         plan.token_counts = tc
         plan.logits_ld = (d["num_classes"] + 7) // 8 * 8
+        plan.resid_bf16 = int(self._resid_bf16)
         nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes

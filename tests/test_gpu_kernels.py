@@ -80,8 +80,9 @@ def test_linear_gelu():
     close(host(y), want, what="linear+gelu")
 
 
+@pytest.mark.parametrize("stream_f32", [False, True])
 @pytest.mark.parametrize("gather", [False, True])
-def test_linear_resid_layerscale(gather):
+def test_linear_resid_layerscale(gather, stream_f32):
     rng = np.random.default_rng(9)
     B, Nsrc, Np, Cc, K = 3, 50, 37, 256, 192
     x = bf16_round_np(rng.standard_normal((B, Np if gather else Nsrc, K), dtype=np.float32))
@@ -90,26 +91,35 @@ def test_linear_resid_layerscale(gather):
     gam = bf16_round_np(rng.standard_normal(Cc, dtype=np.float32))
     resid = bf16_round_np(rng.standard_normal((B, Nsrc, Cc), dtype=np.float32))
     idx = np.stack([np.sort(rng.choice(Nsrc, Np, replace=False)) for _ in range(B)]).astype(np.int32)
+    if stream_f32:   # fp32 residual stream: residual values need not be bf16 representable
+        resid = resid + rng.standard_normal(resid.shape, dtype=np.float32) * 1e-3
+    rdev = torch.from_numpy(resid).to(DEV) if stream_f32 else dev_bf16(resid)
     y = ops.linear(dev_bf16(x), ops.pack_weight(dev_bf16(w)), Cc, torch.from_numpy(b).to(DEV), nat.EPI_BIAS_RESID,
-                   gamma=torch.from_numpy(gam).to(DEV), resid=dev_bf16(resid),
+                   gamma=torch.from_numpy(gam).to(DEV), resid=rdev,
                    r_idx=torch.from_numpy(idx).to(DEV) if gather else None)
     lin = x.astype(np.float64) @ w.astype(np.float64).T + b
     r = orc.gather_rows(resid.astype(np.float64), idx.astype(np.int64)) if gather else resid
     want = r + gam * lin
-    close(host(y).reshape(want.shape), want, what="linear+resid")
+    assert y.dtype == (torch.float32 if stream_f32 else torch.bfloat16)
+    close(host(y).reshape(want.shape), want, rel=1e-5 if stream_f32 else 1e-2, what="linear+resid")
 
 
 # ---------------------------------------------------------------------------------------------
 # LayerNorm, gather
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("x_f32", [False, True])
 @pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (33, 1024), (2, 128)])
-def test_layernorm(rows, Cc):
+def test_layernorm(rows, Cc, x_f32):
     rng = np.random.default_rng(rows)
-    x = bf16_round_np(rng.standard_normal((rows, Cc), dtype=np.float32) * 2 + 0.5)
+    x = rng.standard_normal((rows, Cc), dtype=np.float32) * 2 + 0.5
+    if not x_f32:
+        x = bf16_round_np(x)
     w = bf16_round_np(1 + 0.1 * rng.standard_normal(Cc, dtype=np.float32))
     b = bf16_round_np(0.1 * rng.standard_normal(Cc, dtype=np.float32))
-    y = ops.layernorm(dev_bf16(x), torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), 1e-6)
+    xd = torch.from_numpy(x).to(DEV) if x_f32 else dev_bf16(x)
+    y = ops.layernorm(xd, torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), 1e-6)
+    assert y.dtype == torch.bfloat16
     close(host(y), orc.layer_norm(x.astype(np.float64), w, b, 1e-6), what="layernorm")
 
 
@@ -236,9 +246,10 @@ def test_attention_online_softmax_spike():
 # patch embed
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("S,P,Cc,B,has_cls", [(64, 16, 128, 3, True), (224, 16, 192, 2, True), (64, 16, 128, 2, False),
                                               (32, 8, 64, 5, True)])
-def test_patch_embed(S, P, Cc, B, has_cls):
+def test_patch_embed(S, P, Cc, B, has_cls, out_f32):
     rng = np.random.default_rng(S + Cc)
     img = bf16_round_np(rng.standard_normal((B, 3, S, S), dtype=np.float32))
     w = bf16_round_np(rng.standard_normal((Cc, 3, P, P), dtype=np.float32) * 0.05)
@@ -247,10 +258,10 @@ def test_patch_embed(S, P, Cc, B, has_cls):
     npatch = (S // P) ** 2
     pos = bf16_round_np(rng.standard_normal((npatch + int(has_cls), Cc), dtype=np.float32))
     x = ops.patch_embed(dev_bf16(img), ops.pack_weight(dev_bf16(w)), torch.from_numpy(b).to(DEV), dev_bf16(cls),
-                        dev_bf16(pos), has_cls, P, Cc)
+                        dev_bf16(pos), has_cls, P, Cc, out_f32=out_f32)
     tok = orc.patch_embed(img.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
     if has_cls:
         want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok], axis=1) + pos[None]
     else:
         want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok + pos[None]], axis=1)
-    close(host(x), want, what="patch embed")
+    close(host(x), want, rel=1e-5 if out_f32 else 1e-2, what="patch embed")
