@@ -1,0 +1,186 @@
+"""CPU-only tests (`-m "not gpu"`): the C-ABI library loads and exports every symbol the header
+declares, the host-side mirror of the reference interface behaves like the reference (names,
+argument meaning, error behaviour), and the product path refuses to run without a device instead of
+falling back."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+import rajni_amd
+from oracle import rajni_oracle as orc
+from rajni_amd import _native as nat, ops, timm_shaped as ts
+from rajni_amd.wrapper.model import normalise_schedule, plan_token_counts
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_public_names_match_reference_surface():
+    # rajni/__init__.py:1-2 and rajni/wrapper/__init__.py:1-3
+    assert {"RAJNIViTWrapper", "evaluate_model"} <= set(rajni_amd.__all__)
+    from rajni_amd.wrapper import RAJNIViTWrapper, RAJNIAttention, compute_importance  # noqa: F401
+    import inspect
+    assert list(inspect.signature(rajni_amd.RAJNIViTWrapper.__init__).parameters)[1:] == ["base_model", "pruning_schedule"]
+    assert list(inspect.signature(rajni_amd.evaluate_model).parameters) == ["model", "dataloader", "device", "max_batches", "warmup"]
+    sig = inspect.signature(rajni_amd.evaluate_model)
+    assert sig.parameters["device"].default == "cuda" and sig.parameters["warmup"].default == 5
+    assert list(inspect.signature(RAJNIAttention.__init__).parameters)[1:] == ["attn", "keep_ratio", "update"]
+    assert list(inspect.signature(compute_importance).parameters) == ["qkv", "num_heads", "eps"]
+
+
+def test_library_exports_every_declared_symbol():
+    """Every `rajni_*(` prototype in include/rajni_hip.h resolves in librajni_hip.so (no compute)."""
+    with open(os.path.join(ROOT, "include", "rajni_hip.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"\b(rajni_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rajni_stream_t"}
+    assert len(declared) >= 15
+    lib = nat.load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
+    assert set(nat.EXPORTED_SYMBOLS) == declared
+    assert lib.rajni_abi_version() == 1
+    assert lib.rajni_profile_class_name(0).decode().startswith("gemm")
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors of the ABI structs: field order/size must match what the C side compiled.
+    The workspace query walks the plan struct on the host, so a layout slip shows here."""
+    import ctypes as C
+    plan = nat.VitPlan()
+    plan.dtype, plan.B, plan.in_chans, plan.img_size, plan.patch_size = nat.RAJNI_BF16, 2, 3, 64, 16
+    plan.C, plan.H, plan.D, plan.depth, plan.hidden, plan.num_classes = 128, 2, 64, 4, 512, 10
+    n0 = 17
+    want = 0
+    a256 = lambda v: (v + 255) // 256 * 256
+    rows = 2 * n0
+    for nbytes in (rows * 128 * 4, rows * 128 * 4, rows * 128 * 2, rows * 384 * 2, rows * 128 * 2, rows * 512 * 2,
+                   2 * 128 * 2, rows * 2):
+        want += a256(nbytes)
+    assert nat.lib().rajni_vit_workspace_bytes(C.byref(plan)) == want
+    plan.resid_bf16 = 1     # LAST field of the struct: proves the whole layout lines up
+    assert nat.lib().rajni_vit_workspace_bytes(C.byref(plan)) == want - 2 * (a256(rows * 128 * 4) - a256(rows * 128 * 2))
+
+
+def test_no_cpu_fallback():
+    m = ts.create_model("vit_micro_patch16_64")
+    w = rajni_amd.RAJNIViTWrapper(m, {1: {"keep_ratio": 0.5}})
+    assert w.get_last_stats() is None                      # model.py:25 before the first forward
+    with pytest.raises(nat.NativeError, match="no CPU fallback"):
+        w(torch.randn(1, 3, 64, 64))
+    with pytest.raises(nat.NativeError):
+        rajni_amd.compute_importance(torch.randn(1, 5, 3 * 128), 2)
+    with pytest.raises(nat.NativeError):
+        w.blocks[1].attn(torch.randn(1, 17, 128))
+    with pytest.raises(nat.NativeError, match="not found"):
+        nat._lib, keep = None, nat._lib
+        try:
+            nat.load_library("/nonexistent/librajni_hip.so")
+        finally:
+            nat._lib = keep
+
+
+def test_wrapper_surgery_matches_reference_semantics():
+    """model.py:12-23: scheduled blocks get RAJNIAttention sharing the timm attention's parameters,
+    every block gets has_pruner, the parameter set is unchanged."""
+    m = ts.create_model("vit_micro_patch16_64")
+    n_params = len(list(m.parameters()))
+    qkv_before = m.blocks[2].attn.qkv
+    w = rajni_amd.RAJNIViTWrapper(m, {2: {"keep_ratio": 0.7, "update": False}, 3: {"keep_ratio": 0.5}})
+    assert [b.has_pruner for b in w.blocks] == [False, False, True, True]
+    assert isinstance(w.blocks[2].attn, rajni_amd.RAJNIAttention) and w.blocks[2].attn.qkv is qkv_before
+    assert w.blocks[2].attn.update is False and w.blocks[3].attn.update is True          # model.py:19
+    assert w.blocks[2].attn.keep_ratio == 0.7 and w.blocks[2].attn.num_heads == 2
+    assert len(list(w.parameters())) == n_params
+    assert w.m is m and w.blocks is m.blocks
+    with pytest.raises(KeyError):                                                         # model.py:18
+        rajni_amd.RAJNIViTWrapper(ts.create_model("vit_micro_patch16_64"), {1: {"update": True}})
+
+
+def test_schedule_json_string_keys_are_normalised():
+    """the reference tests `i in schedule` with int i against JSON string keys and never
+    prunes; the build normalises.  schedule.json's content is restated here as data."""
+    sched = json.loads('{"3": {"keep_ratio": 0.95, "update": false}, "4": {"keep_ratio": 0.95, "update": true},'
+                       ' "5": {"keep_ratio": 0.85, "update": true}, "6": {"keep_ratio": 0.85, "update": true},'
+                       ' "7": {"keep_ratio": 0.95, "update": true}}')
+    norm = normalise_schedule(sched)
+    assert sorted(norm) == [3, 4, 5, 6, 7] and norm[3]["update"] is False
+    # SURVEY Q1 value for schedule.json with int keys
+    assert plan_token_counts(197, 12, norm) == [197, 197, 197, 197, 187, 177, 150, 127, 120, 120, 120, 120]
+    assert plan_token_counts(197, 12, norm) == orc.token_counts(197, 12, orc.normalise_schedule(sched))
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(2, 1500), st.floats(0.0, 1.0, allow_nan=False))
+def test_keep_count_is_python_double_truncation(n, ratio):
+    assert ops.keep_count(ratio, n) == max(1, int(ratio * (n - 1))) == orc.keep_count(ratio, n)
+    assert 1 <= ops.keep_count(ratio, n) <= max(1, n - 1)
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(2, 600), st.integers(1, 24),
+       st.dictionaries(st.integers(0, 23), st.floats(0.05, 1.0, allow_nan=False), max_size=6))
+def test_token_counts_plan_matches_oracle(n0, depth, ratios):
+    sched = {k: {"keep_ratio": v} for k, v in ratios.items()}
+    assert plan_token_counts(n0, depth, normalise_schedule(sched)) == orc.token_counts(n0, depth, orc.normalise_schedule(sched))
+
+
+def test_readme_schedule_counts():
+    sched = {3: {"keep_ratio": 0.88}, 4: {"keep_ratio": 0.88}, 7: {"keep_ratio": 0.8}, 8: {"keep_ratio": 0.72}}
+    assert plan_token_counts(197, 12, normalise_schedule(sched)) == [197, 197, 197, 197, 173, 152, 152, 152, 121, 87, 87, 87]
+    agg = {4: {"keep_ratio": 0.7}, 12: {"keep_ratio": 0.5}, 20: {"keep_ratio": 0.3}}
+    assert plan_token_counts(577, 24, normalise_schedule(agg)) == [577] * 5 + [404] * 8 + [202] * 8 + [61] * 3
+
+
+class _Counting(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.calls = 0
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        self.calls += 1
+        return x
+
+
+def test_evaluate_model_matches_reference_fixture():
+    """eval.py:6-75 bookkeeping, against outcomes captured from the reference's evaluate_model."""
+    with open(os.path.join(GOLDEN, "evaluate_cases.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        loader = [(torch.tensor(a, dtype=torch.float32), torch.tensor(b)) for a, b in zip(c["logits"], c["labels"])]
+        m = _Counting()
+        acc, thr = rajni_amd.evaluate_model(m, loader, device="cpu", max_batches=c["max_batches"], warmup=c["warmup"])
+        assert acc == pytest.approx(c["acc"], abs=1e-9)
+        assert m.calls == c["forwards"]
+        assert thr > 0
+
+
+def test_evaluate_model_accepts_generators_without_len():
+    def gen():
+        for _ in range(3):
+            yield torch.eye(4), torch.arange(4)
+
+    class Loader:
+        def __iter__(self):
+            return gen()
+
+    acc, thr = rajni_amd.evaluate_model(_Counting(), Loader(), device="cpu", max_batches=None, warmup=1)
+    assert acc == 100.0
+
+
+def test_oracle_is_not_imported_by_the_product():
+    """The product package must never import oracle/ (prompt section 3)."""
+    pkg = os.path.join(ROOT, "rajni-vit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+                assert "rajni_oracle" not in src, fn
