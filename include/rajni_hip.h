@@ -90,7 +90,7 @@ int rajni_layernorm(const void* x, long x_row_stride, const float* w, const floa
 
 /* ---- linear layers with fused epilogues (a3, a9, a13, a15) ----
  * y[M,N] = epi(x[M,K] W[N,K]^T).  W must be allocated with its row count padded up to a multiple
- * of 128 (rows >= N are never read into results but must be readable); K % 64 == 0; lda/ldw/ldc/ldr
+ * of 256 (rows >= N are never read into results but must be readable); K % 64 == 0; lda/ldw/ldc/ldr
  * in elements, multiples of 8.  bias/gamma are fp32 [N] (NULL = 0 / 1).
  * RESID: resid row for output row m is  (m / r_np) * r_nsrc + r_idx[m]  when r_idx != NULL
  * (r_idx = keep_idx flattened [B*r_np]), else m. */
@@ -108,9 +108,14 @@ typedef struct {
   int stream_f32;  /* RESID only: resid and y are the fp32 residual stream (1) instead of `dtype` (0) */
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
+/* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 2-stage, 2 = 256x128x32 pipelined, 3 = 128x128x32 pipelined, 4 = 256x256x64 (8 waves) */
+void rajni_debug_force_gemm_tiling(int mode);
+/* diagnostic builds (-DRAJNI_GEMM_STAMPS) only: device buffer receiving 4 x uint64 s_memtime stamps per
+ * workgroup of the 256x256 GEMM (start, main loop start, main loop end, end); NULL disables */
+void rajni_debug_set_gemm_stamps(void* buf);
 
 /* ---- a12: patch-embed + CLS + pos-embed                                    model.py:34-37 ----
- * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad128), Cin*P*P] (k order c,ky,kx),
+ * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad256), Cin*P*P] (k order c,ky,kx),
  * bias fp32 [C]; cls [C]; pos [(1 or 0)+(S/P)^2, C] (`pos_has_cls`=0 is timm no_embed_class:
  * SURVEY B3); x is written as fp32 when x_f32 != 0.  The im2col is fused into the GEMM's tile loads.  P % 8 == 0, S % P == 0. */
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,

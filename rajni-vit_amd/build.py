@@ -20,7 +20,12 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra=()):
+def build(force=False, verbose=True, extra=(), out=None):
+    """`out`/`extra` build an experimental variant (e.g. -DRAJNI_GEMM_X_AUX=2) next to the default."""
+    global OUT
+    if out is not None:
+        OUT = out
+        force = True
     if not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -28,7 +33,7 @@ def build(force=False, verbose=True, extra=()):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, (os.path.basename(OUT) + "." if out is not None else "") + src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
                "-c", os.path.join(CSRC, src), "-o", obj, *extra]
         if verbose:

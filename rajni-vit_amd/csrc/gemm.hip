@@ -2,11 +2,10 @@
 //
 //   Y[m][n] = epi( sum_k X[m][k] * W[n][k] )        X = activations [M,K], W = torch Linear weight [N,K]
 //
-// gfx950 design (v1: 128x128x64 tile, 4 waves, 2 workgroups per CU):
+// Common gfx950 design:
 //   * both operands are K-contiguous, so every MFMA fragment is one 16-byte LDS read;
-//   * tiles are staged HBM->LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction),
-//     double buffered, one barrier per 64-deep K step;
-//   * the LDS image is XOR-swizzled on the SOURCE address (LDS-DMA writes lane-linear), the same
+//   * tiles are staged HBM->LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction);
+//     the LDS image is XOR-swizzled on the SOURCE address (LDS-DMA writes lane-linear) and the same
 //     involution is applied on the fragment reads -> conflict-free ds_read_b128;
 //   * v_mfma_f32_16x16x32_bf16 with W as the A operand and X as the B operand, so that a lane owns
 //     ONE output row m and - through a permutation of which W row feeds which fragment row -
@@ -14,17 +13,19 @@
 //     per-row epilogue data (gathered residual row, patch->token row remap) is per-lane constant;
 //   * workgroup -> tile mapping walks N fastest inside an XCD-contiguous chunk, so the X panel of a
 //     tile row is fetched from HBM once per XCD and W stays L2-resident.
+//
+// Tilings (chosen per launch, see launch_gemm):
+//   pipe<8> 256(M) x 128(N) x 32(K), 4 waves each owning 128x64, 3 LDS stages (72 KiB, 2 workgroups
+//           per CU), register-double-buffered fragments, LDS reads + LDS-DMA interleaved with MFMAs;
+//   pipe<4> 128 x 128 x 32, same pipeline, wave tile 64x64 (48 KiB, 3 workgroups per CU);
+//   small   128 x 128 x 64, 2 stages, one barrier + drain per step - for M < 1024 (head, tiny batches).
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
 enum { ALOAD_PLAIN = 0, ALOAD_PATCH = 1 };
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // X + W
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
 
 struct GemmParams {
   const bf16_t* X; long lda;
@@ -39,26 +40,31 @@ struct GemmParams {
   // patch-embed A loader / epilogue
   int cin, S, log2ps, gw, npatch;
   const bf16_t* pos; int pos_off;
+  unsigned long long* stamps;   // diagnostic builds only (RAJNI_GEMM_STAMPS): 4 s_memtime values per block
 };
 
-// swizzle keys (3 bits) of a tile row; must give 16 distinct LDS slots to the 16 rows one
-// ds_read_b128 lane group touches (row stride 128 B, bank row 256 B -> slot = (row&1)*8 + chunk^key)
-__device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
-// W fragment rows are read permuted: {16a + 4*ni + b : a,b in 0..3}
-__device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
-
-__device__ __forceinline__ float gelu_erf(float x) {
-  // exact-erf GELU (timm nn.GELU()); erf by Abramowitz-Stegun 7.1.26, |err| < 1.5e-7
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = 1.0f - poly * __expf(-z * z);
-  const float erfv = copysignf(e, x);
-  return 0.5f * x * (1.0f + erfv);
+// exact-erf GELU (timm nn.GELU()) for the bf16 path, two values per instruction (v_pk_*_f32, no
+// transcendentals):  gelu(x) = x*(0.5 + h(x)),  h(x) = 0.5*erf(x/sqrt2) ~= xc*P(xc^2),
+// xc = clamp(x, +-3*sqrt2), P = degree-8 least-squares fit on Chebyshev nodes (coefficients from
+// tools/fit_gelu.py).  |gelu error| <= 4.3e-5 absolute - 1/50 of a bf16 ulp at |y| ~ 1 - measured
+// against fp64 erf over [-8, 8].  The FC1 epilogue is VALU bound: the previous exp+rcp form
+// (Abramowitz-Stegun 7.1.26) cost ~20k cycles per 256x256 tile, a third of the tile's time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+  const float X0 = 4.24264069f;
+  f32x2 xc = __builtin_elementwise_min(__builtin_elementwise_max(x, f32x2{-X0, -X0}), f32x2{X0, X0});
+  const f32x2 u = xc * xc;
+  f32x2 q = f32x2{5.405088552e-11f, 5.405088552e-11f};
+  q = q * u + f32x2{-5.202485173e-09f, -5.202485173e-09f};
+  q = q * u + f32x2{2.215015442e-07f, 2.215015442e-07f};
+  q = q * u + f32x2{-5.557312053e-06f, -5.557312053e-06f};
+  q = q * u + f32x2{9.274613401e-05f, 9.274613401e-05f};
+  q = q * u + f32x2{-1.104852507e-03f, -1.104852507e-03f};
+  q = q * u + f32x2{9.805144109e-03f, 9.805144109e-03f};
+  q = q * u + f32x2{-6.633033261e-02f, -6.633033261e-02f};
+  q = q * u + f32x2{3.988969665e-01f, 3.988969665e-01f};
+  const f32x2 h = xc * q;
+  return x * h + x * f32x2{0.5f, 0.5f};
 }
 
 // load / store 16 consecutive stream elements (bf16 or fp32) as floats
@@ -96,67 +102,546 @@ __device__ __forceinline__ void store1(void* base, long off, float v) {
   else reinterpret_cast<bf16_t*>(base)[off] = f2bf(v);
 }
 
-// SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32
-template <int EPI, int ALOAD, bool SF32>
-__global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-  // ---- XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous tile range
-  const int total = p.total_tiles;
-  const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- staging addresses: wave w stages pieces 4w..4w+3 of each operand; a piece = 8 rows x 128 B
-  const int r_in = lane >> 3, pch = lane & 7;
-  const bf16_t* xsrc[4];
-  const bf16_t* wsrc[4];
-  int xk[4];  // patch loader: this lane's k offset inside a K step (elements)
+// One output row m, columns nb..nb+15 (v = accumulators + bias on entry).
+// SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32.
+template <int EPI, bool SF32>
+__device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb, float* v, const float* gam) {
+  long orow = m;
+  if (EPI == EPI_GELU) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + r_in;
-    const int cx = pch ^ key_x(row);
-    const int cw = pch ^ key_w(row);
-    int m = m0 + row;
-    if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
+    for (int j = 0; j < 16; j += 2) {
+      const f32x2 y = gelu_pk(f32x2{v[j], v[j + 1]});
+      v[j] = y[0]; v[j + 1] = y[1];
+    }
+  } else if (EPI == EPI_RESID) {
+    long rrow = m;
+    if (p.ridx != nullptr) {
+      const int b = m / p.r_np;
+      rrow = (long)b * p.r_nsrc + p.ridx[m];
+    }
+    const long roff = rrow * p.ldr + nb;
+    if (nb + 16 <= p.N) {
+      float rf[16];
+      load16<SF32>(p.R, roff, rf);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = fmaf(gam[j], v[j], rf[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], load1<SF32>(p.R, roff + j));
+    }
+  } else if (EPI == EPI_PATCH) {
+    const int b = m / p.npatch, pp = m - b * p.npatch;
+    orow = (long)b * (p.npatch + 1) + 1 + pp;
+    const bf16_t* pr = p.pos + (long)(pp + p.pos_off) * p.ldc + nb;
+    if (nb + 16 <= p.N) {
+      float pf[16];
+      unpack8(*reinterpret_cast<const uint4*>(pr), pf);
+      unpack8(*reinterpret_cast<const uint4*>(pr + 8), pf + 8);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] += pf[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < p.N) v[j] += bf2f(pr[j]);
+    }
+  }
+  constexpr bool OUT32 = SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH);
+  const long yoff = orow * p.ldc + nb;
+  if (nb + 16 <= p.N) {
+    store16<OUT32>(p.Y, yoff, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (nb + j < p.N) store1<OUT32>(p.Y, yoff + j, v[j]);
+  }
+}
+
+// XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous range of tiles
+__device__ __forceinline__ int xcd_tile_of(int v, int total) {
+  const int q = total >> 3, r = total & 7, xcd = v & 7, loc = v >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+__device__ __forceinline__ int xcd_tile(int total) { return xcd_tile_of(blockIdx.x, total); }
+
+// global source of the 16-byte chunk (row m, K offset k..k+7) of the X operand
+template <int ALOAD>
+struct XSource {
+  const bf16_t* base;  // PLAIN: row pointer (+ swizzled chunk); PATCH: patch origin in the image
+  int kofs;            // PATCH: this lane's k offset inside a K step
+  __device__ __forceinline__ void init(const GemmParams& p, int m, int chunk) {
     if (ALOAD == ALOAD_PLAIN) {
-      xsrc[i] = p.X + (long)m * p.lda + cx * 8;
-      xk[i] = 0;
+      base = p.X + (long)m * p.lda + chunk * 8;
+      kofs = 0;
     } else {
       const int b = m / p.npatch, pp = m - b * p.npatch;
       const int py = pp / p.gw, px = pp - py * p.gw;
-      xsrc[i] = p.X + ((long)b * p.cin * p.S + (py << p.log2ps)) * p.S + (px << p.log2ps);
-      xk[i] = cx * 8;
+      base = p.X + ((long)b * p.cin * p.S + (py << p.log2ps)) * p.S + (px << p.log2ps);
+      kofs = chunk * 8;
     }
-    wsrc[i] = p.W + (long)(n0 + row) * p.ldw + cw * 8;  // W rows are padded to a multiple of 128
+  }
+  __device__ __forceinline__ const bf16_t* at(const GemmParams& p, int k0) const {
+    if (ALOAD == ALOAD_PLAIN) return base + k0;
+    const int k = k0 + kofs, ps2 = 2 * p.log2ps;
+    const int ch = k >> ps2, rem = k & ((1 << ps2) - 1);
+    const int ky = rem >> p.log2ps, kx = rem & ((1 << p.log2ps) - 1);
+    return base + ((long)ch * p.S + ky) * p.S + kx;
+  }
+};
+
+// =============================================================================================
+// pipelined tiling: (32*MI)(M) x 128(N) x 32(K), 3 LDS stages, fragments double-buffered in registers
+//   MI = 8: 256 x 128 tile, wave tile 128 x 64 (72 KiB LDS, 2 workgroups per CU)
+//   MI = 4: 128 x 128 tile, wave tile  64 x 64 (48 KiB LDS, 3 workgroups per CU) - used when the
+//           256-row tiling would leave most CUs idle in its last round (N = 768 outputs)
+// Per K step a wave issues, INTERLEAVED between its MFMAs (sched_group_barrier): the LDS reads of
+// the NEXT step's fragments into the other register set and the LDS-DMA pieces of the step three
+// ahead.  One raw s_barrier per step; DMA completion by counted vmcnt (never 0 in the main loop).
+// =============================================================================================
+namespace pipe {
+constexpr int BN = 128, BK = 32, STAGES = 3;
+constexpr int W_BYTES = BN * BK * 2;            //  8 KiB
+// 64-byte rows: 4 rows per 256-byte bank row, slot = (row&3)*4 + (chunk ^ key).  The 16 rows of one
+// ds_read_b128 lane group come as {4 rows @chunk c} u {4 rows @c} u {8 rows @c^1}; the keys below
+// make the 16 slots distinct (derivation in DESIGN.md "LDS swizzles").
+__device__ __forceinline__ int key_x(int row) { return (-(row >> 2)) & 3; }   // natural rows base + (lane&15)
+__device__ __forceinline__ int key_w(int row) { return (-(row >> 4)) & 3; }   // permuted rows 16a + 4ni + b
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12, "unsupported vmcnt");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// compile-time issue order of one K step: NG groups of {4 MFMAs, 1 X (+1 W in the first 4 groups)
+// fragment read of the next step, 1 DMA piece in the first DM groups}
+template <int G, int NG, bool READ, int DM>
+__device__ __forceinline__ void sched_steps() {
+  if constexpr (G < NG) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, G < 4 ? 2 : 1, 0);
+    if constexpr (G < DM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    sched_steps<G + 1, NG, READ, DM>();
+  }
+}
+
+template <int MI> struct Cfg {
+  static constexpr int BM = 32 * MI;
+  static constexpr int X_BYTES = BM * BK * 2;
+  static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int XP = MI / 2;          // X pieces (1 KiB) per wave per K step
+  static constexpr int PIECES = XP + 2;      // + 2 W pieces
+};
+
+template <int EPI, int ALOAD, bool SF32, int MI>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) {
+  using C = Cfg<MI>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_tile(p.total_tiles);
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * BN;
+
+  // ---- staging: a piece = one wave instruction = 1 KiB = 16 rows x 64 B
+  const int r_in = lane >> 2, pos = lane & 3;
+  XSource<ALOAD> xs[C::XP];
+  const bf16_t* ws[2];
+#pragma unroll
+  for (int i = 0; i < C::XP; ++i) {
+    const int row = (wave * C::XP + i) * 16 + r_in;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
+    xs[i].init(p, m, pos ^ key_x(row));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + r_in;
+    ws[i] = p.W + (long)(n0 + row) * p.ldw + (pos ^ key_w(row)) * 8;  // W rows padded to 128
+  }
+  auto stage = [&](int kt, int st) {
+    char* sx = smem + st * C::STAGE_BYTES;
+    char* sw = sx + C::X_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < C::XP; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * C::XP + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets (bytes inside a stage), K-step invariant
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  int xoff[MI], woff[4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int xr = wm * (16 * MI) + i * 16 + l15;
+    xoff[i] = xr * 64 + ((g ^ key_x(xr)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int wr = wn * 64 + 16 * (l15 >> 2) + i * 4 + (l15 & 3);
+    woff[i] = C::X_BYTES + wr * 64 + ((g ^ key_w(wr)) << 4);
   }
 
+  f32x4 acc[4][MI];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto read_frags = [&](int st, bf16x8 (&xf)[MI], bf16x8 (&wf)[4]) {
+    const char* sb = smem + st * C::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + woff[i]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff[i]);
+  };
+  auto mma = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  };
+  // One K step: compute tile kt from (xc,wc); meanwhile read tile kt+1 (stage st1) into (xn,wn_)
+  // and DMA tile kt+3 into the stage tile kt just vacated (st0).
+  //   ISSUE: tile kt+3 exists.  WAIT: pieces that may stay in flight while tile kt+1 must have landed
+  //   (-1: nothing to wait for).  READ: tile kt+1 exists.
+  auto phase = [&](auto issue_c, auto wait_c, auto read_c, bf16x8 (&xc)[MI], bf16x8 (&wc)[4],
+                   bf16x8 (&xn)[MI], bf16x8 (&wn_)[4], int kt, int st0, int st1) {
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    constexpr int WAIT = decltype(wait_c)::value;
+    constexpr bool READ = decltype(read_c)::value;
+    if constexpr (READ) {
+      // my reads of tile kt (issued last step) are complete, my DMA pieces of tile kt+1 have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<WAIT>();
+      __builtin_amdgcn_s_barrier();  // ... and so have everyone else's: tile kt+1 readable, stage st0 free
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (ISSUE) stage(kt + 3, st0);
+    // Group mi: 4 MFMAs on xc[mi], then the read of xn[mi] - which may land in the registers xc[mi]
+    // just vacated, so one X fragment set + two W sets are live (~200 VGPRs, not 250) - plus one W
+    // fragment read (first 4 groups) and one DMA piece (first PIECES groups).
+    const char* sb = smem + st1 * C::STAGE_BYTES;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);
+      if constexpr (READ) {
+        xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xoff[mi]);
+        if (mi < 4) wn_[mi] = *reinterpret_cast<const bf16x8*>(sb + woff[mi]);
+      }
+    }
+    sched_steps<0, MI, READ, ISSUE ? C::PIECES : 0>();
+  };
+  using T = std::true_type; using F = std::false_type;
+  constexpr int PC = C::PIECES;
+
+  const int nk = p.K / BK;   // even, >= 2
+  bf16x8 xa[MI], wa[4], xb[MI], wb[4];
+  stage(0, 0);
+  stage(1, 1);
+  if (nk > 2) { stage(2, 2); wait_vmcnt<2 * PC>(); } else { wait_vmcnt<PC>(); }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, xa, wa);
+  int st = 0;  // stage of tile kt
+  auto nxt = [](int s3) { return s3 == 2 ? 0 : s3 + 1; };
+  int kt = 0;
+  for (; kt < nk - 4; kt += 2) {
+    const int s1 = nxt(st), s2 = nxt(s1);
+    phase(T{}, std::integral_constant<int, PC>{}, T{}, xa, wa, xb, wb, kt, st, s1);
+    phase(T{}, std::integral_constant<int, PC>{}, T{}, xb, wb, xa, wa, kt + 1, s1, s2);
+    st = s2;
+  }
+  if (nk >= 4) {  // kt == nk - 4: tile kt+3 is the last one
+    const int s1 = nxt(st), s2 = nxt(s1);
+    phase(T{}, std::integral_constant<int, PC>{}, T{}, xa, wa, xb, wb, kt, st, s1);
+    phase(F{}, std::integral_constant<int, PC>{}, T{}, xb, wb, xa, wa, kt + 1, s1, s2);
+    st = s2;
+    kt += 2;
+  }
+  {  // kt == nk - 2
+    const int s1 = nxt(st);
+    phase(F{}, std::integral_constant<int, 0>{}, T{}, xa, wa, xb, wb, kt, st, s1);
+    phase(F{}, std::integral_constant<int, 0>{}, F{}, xb, wb, xa, wa, kt + 1, s1, st);
+  }
+
+  // ---- epilogue: lane owns row m and columns nb .. nb+15
+  const int nb = n0 + wn * 64 + 16 * g;
+  float bias[16], gam[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = nb + j;
+    bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm * (16 * MI) + mi * 16 + l15;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+    epilogue_row<EPI, SF32>(p, m, nb, v, gam);
+  }
+}
+}  // namespace pipe
+
+// =============================================================================================
+// wide tiling: 256(M) x 256(N) x 64(K), 8 waves (2 x 4) each owning 128 x 64, 2 LDS stages = 128 KiB,
+// one workgroup per CU.  Measured on the chip (tools/mfma_probe.hip, profiles/): the 128-wide tilings
+// are bound by the CU's load path (bytes staged per FLOP), not by MFMA issue or LDS; this tile stages
+// 16 KiB per 2.1 MFLOP (the 128x128 tile: 32 KiB) in full 128-byte lines.
+// K step kt (stage s = kt&1), registers holding the ks=0 fragments of tile kt on entry:
+//   half 1: MFMAs(kt,ks0)  ||  LDS reads of (kt,ks1)
+//   s_waitcnt lgkmcnt(0) vmcnt(0) ; s_barrier      -> stage s is free, tile kt+1 (stage s^1) has landed
+//   half 2: MFMAs(kt,ks1)  ||  LDS reads of (kt+1,ks0)  ||  LDS-DMA of tile kt+2 into stage s
+// One barrier per 64 MFMAs per wave; every LDS read and DMA issue sits between MFMAs.
+// =============================================================================================
+#ifndef RAJNI_GEMM_X_AUX
+#define RAJNI_GEMM_X_AUX 0   // cache-policy bits of the X (activation) LDS-DMA loads: 2 = nt
+#endif
+#ifndef RAJNI_GEMM_W_AUX
+#define RAJNI_GEMM_W_AUX 0   // ... of the W (weight) loads
+#endif
+namespace wide {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
+constexpr int STAGE_BYTES = 2 * X_BYTES;        // 64 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // 128 KiB
+__device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
+
+// issue order of one half step: 8 groups of {4 MFMAs, 1 X (+1 W in the first 4 groups) fragment read,
+// 1 DMA piece}
+template <int G, bool READ, bool DMA>
+__device__ __forceinline__ void sched_half() {
+  if constexpr (G < 8) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, G < 4 ? 2 : 1, 0);
+    if constexpr (DMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    sched_half<G + 1, READ, DMA>();
+  }
+}
+
+template <int EPI, int ALOAD, bool SF32>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X and W pieces 4w..4w+3
+  const int r_in = lane >> 3, pch = lane & 7;
+  XSource<ALOAD> xs[4];
+  const bf16_t* ws[4];
+  auto point_at = [&](int tile) {   // DMA source pointers of a tile
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + r_in;
+      int m = tm * BM + row;
+      if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
+      xs[i].init(p, m, pch ^ key_x(row));
+      ws[i] = p.W + (long)(tn * BN + row) * p.ldw + (pch ^ key_w(row)) * 8;  // W rows padded to 256
+    }
+  };
+  auto stage = [&](int kt, int st) {
+    char* sx = smem + st * STAGE_BYTES;
+    char* sw = sx + X_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+    }
+  };
+
+  // ---- fragment addresses: rows base + (lane&15) have key (lane&15)>>1 for every mi, the permuted
+  //      W rows have one key for every ni, so each (operand, ks) needs ONE address + immediates
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int xr0 = wm * 128 + l15;
+  const int wr0 = wn * 64 + 16 * (l15 >> 2) + (l15 & 3);
+  int xo[2], wo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    xo[ks] = xr0 * 128 + (((ks * 4 + g) ^ key_x(xr0)) << 4);
+    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ key_w(wr0)) << 4);
+  }
+
+  f32x4 acc[4][8];  // [ni][mi]
+
+  // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
+  // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage
+  // dst, one piece per MFMA group
+  auto half = [&](auto dma_c, bf16x8 (&xc)[8], bf16x8 (&wc)[4], bf16x8 (&xn)[8], bf16x8 (&wn_)[4],
+                  int rst, int rks, int dkt, int dst) {
+    constexpr bool DMA = decltype(dma_c)::value;
+    const char* sb = smem + rst * STAGE_BYTES;
+    char* dx = smem + dst * STAGE_BYTES + wave * 4096;
+    const int k0 = dkt * BK;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);
+      xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
+      if (mi < 4) wn_[mi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + mi * 512);
+      if constexpr (DMA) {  // piece mi of this wave: X pieces 0..3 then W pieces 0..3
+        if (mi < 4)
+          __builtin_amdgcn_global_load_lds(GLB_PTR(xs[mi].at(p, k0)), LDS_PTR(dx + mi * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+        else
+          __builtin_amdgcn_global_load_lds(GLB_PTR(ws[mi - 4] + k0), LDS_PTR(dx + X_BYTES + (mi - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+      }
+    }
+    sched_half<0, true, DMA>();
+  };
+  using T = std::true_type; using F = std::false_type;
+
+  // ---- persistent: this workgroup walks tiles v = blockIdx.x, +gridDim.x, ... as ONE stream of K
+  //      steps.  The DMA runs two steps ahead of the MFMAs ACROSS tile boundaries, so the next tile's
+  //      first loads are in flight while this tile's epilogue runs.
+  const int nk = p.K / BK;        // >= 3 (host checked)
+  int v = blockIdx.x;
+  int tile = xcd_tile_of(v, p.total_tiles);
+  bf16x8 xa[8], wa[4], xb[8], wb[4];
+  point_at(tile);
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + i * 512);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
+  int par = 0;  // LDS stage of the current K step
+
+  while (true) {
+#ifdef RAJNI_GEMM_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int vn = v + gridDim.x;
+    const bool more = vn < p.total_tiles;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // the DMA of step kt loads K-tile kt+2; from kt = nk-2 on that is the NEXT tile's K-tile 0/1
+      // (when there is no next tile the pointers stay put: harmless re-loads that nobody reads)
+      if (kt == nk - 2 && more) point_at(xcd_tile_of(vn, p.total_tiles));
+      const int dkt = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+      half(F{}, xa, wa, xb, wb, par, 1, 0, 0);
+      // my reads of stage `par` are done and my DMA pieces of the next step have landed ...
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage par is free, stage par^1 readable
+      asm volatile("" ::: "memory");
+      half(T{}, xb, wb, xa, wa, par ^ 1, 0, dkt, par);
+      par ^= 1;
+    }
+#ifdef RAJNI_GEMM_STAMPS
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][7][3]));
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- epilogue: lane owns row m and columns nb .. nb+15 (next tile's loads are in flight)
+    const int nb = n0 + wn * 64 + 16 * g;
+    float bias[16], gam[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = nb + j;
+      bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+      gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int m = m0 + wm * 128 + mi * 16 + l15;
+      if (m >= p.M) continue;
+      float vv[16];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) vv[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+      epilogue_row<EPI, SF32>(p, m, nb, vv, gam);
+    }
+#ifdef RAJNI_GEMM_STAMPS
+    if (p.stamps != nullptr && wave == 0) {
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        unsigned long long* o = p.stamps + (size_t)tile * 4;
+        o[0] = ts0; o[1] = ts0; o[2] = ts2; o[3] = ts3;
+      }
+    }
+#endif
+    if (!more) break;
+    v = vn;
+    tile = xcd_tile_of(v, p.total_tiles);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing (unused) DMA before LDS is released
+}
+}  // namespace wide
+
+// =============================================================================================
+// small tiling: 128 x 128 x 64, 2 stages
+// =============================================================================================
+namespace small {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // X + W
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // double buffered: 64 KiB
+// 128-byte rows: slot = (row&1)*8 + (chunk ^ key)
+__device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
+
+template <int EPI, int ALOAD, bool SF32>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_tile(p.total_tiles);
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging: wave w stages pieces 4w..4w+3 of each operand; a piece = 8 rows x 128 B
+  const int r_in = lane >> 3, pch = lane & 7;
+  XSource<ALOAD> xs[4];
+  const bf16_t* ws[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + r_in;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    xs[i].init(p, m, pch ^ key_x(row));
+    ws[i] = p.W + (long)(n0 + row) * p.ldw + (pch ^ key_w(row)) * 8;
+  }
   auto stage = [&](int kt, int buf) {
     char* sx = smem + buf * STAGE_BYTES;
     char* sw = sx + TILE_BYTES;
     const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16_t* src;
-      if (ALOAD == ALOAD_PLAIN) {
-        src = xsrc[i] + k0;
-      } else {
-        const int k = k0 + xk[i];
-        const int ps2 = 2 * p.log2ps;
-        const int ch = k >> ps2, rem = k & ((1 << ps2) - 1);
-        const int ky = rem >> p.log2ps, kx = rem & ((1 << p.log2ps) - 1);
-        src = xsrc[i] + ((long)ch * p.S + ky) * p.S + kx;
-      }
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, 0);
   };
 
-  // ---- fragment read offsets (bytes inside a tile), K-step invariant
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
   int xoff[4], xkey[4], woff[4], wkey[4];
@@ -199,7 +684,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
     }
   }
 
-  // ---- epilogue: lane owns row m and columns nb .. nb+15
   const int nb = n0 + wn * 64 + 16 * g;
   float bias[16], gam[16];
 #pragma unroll
@@ -217,54 +701,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn(const GemmParams p) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-
-    long orow = m;
-    if (EPI == EPI_GELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-    } else if (EPI == EPI_RESID) {
-      long rrow = m;
-      if (p.ridx != nullptr) {
-        const int b = m / p.r_np;
-        rrow = (long)b * p.r_nsrc + p.ridx[m];
-      }
-      const long roff = rrow * p.ldr + nb;
-      if (nb + 16 <= p.N) {
-        float rf[16];
-        load16<SF32>(p.R, roff, rf);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = fmaf(gam[j], v[j], rf[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], load1<SF32>(p.R, roff + j));
-      }
-    } else if (EPI == EPI_PATCH) {
-      const int b = m / p.npatch, pp = m - b * p.npatch;
-      orow = (long)b * (p.npatch + 1) + 1 + pp;
-      const bf16_t* pr = p.pos + (long)(pp + p.pos_off) * p.ldc + nb;
-      if (nb + 16 <= p.N) {
-        float pf[16];
-        unpack8(*reinterpret_cast<const uint4*>(pr), pf);
-        unpack8(*reinterpret_cast<const uint4*>(pr + 8), pf + 8);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] += pf[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (nb + j < p.N) v[j] += bf2f(pr[j]);
-      }
-    }
-    const long yoff = orow * p.ldc + nb;
-    if (nb + 16 <= p.N) {
-      store16<SF32>(p.Y, yoff, v);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (nb + j < p.N) store1<SF32>(p.Y, yoff + j, v[j]);
-    }
+    epilogue_row<EPI, SF32>(p, m, nb, v, gam);
   }
 }
+}  // namespace small
 
 // x[b,0,:] = cls + pos[0]  (or cls alone when pos has no CLS row)
 template <bool SF32>
@@ -278,31 +718,85 @@ __global__ void cls_pos_kernel(const bf16_t* cls, const bf16_t* pos, int pos_has
   store1<SF32>(x, (long)b * img_stride + c, v);
 }
 
-template <int EPI, int ALOAD, bool SF32>
-int launch_gemm(const GemmParams& p, int kclass, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tn<EPI, ALOAD, SF32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    if (e != hipSuccess) {
-      rajni_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
-      return RAJNI_ERR_LAUNCH;
-    }
-    attr_set = true;
+unsigned long long* g_stamps = nullptr;
+int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
+int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64 (tests)
+
+template <typename K>
+int set_lds_attr(K kernel, int lds, bool& done) {
+  if (done) return RAJNI_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) {
+    rajni_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+    return RAJNI_ERR_LAUNCH;
   }
+  done = true;
+  return RAJNI_OK;
+}
+
+// rounds of workgroups a launch needs on 256 CUs at `per_cu` resident workgroups each, weighted by
+// the tile's relative duration: picks the tiling that finishes first
+inline double launch_cost(int tiles, int per_cu, double tile_time) {
+  const int slots = 256 * per_cu;
+  return ((tiles + slots - 1) / slots) * tile_time;
+}
+
+template <int EPI, int ALOAD, bool SF32>
+int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
+  p.stamps = g_stamps;
+  p.tiles_n = (p.N + 127) / 128;
+  const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
+  int mode = g_force_tiling;
+  if (mode == 4 && p.K < 192) mode = 2;   // the persistent 256x256 stream needs >= 3 K steps
+  if (mode == 0) {
+    // measured on ViT-B shapes (tools/gemm_bench.py, profiles/): the persistent 256x256 tiling wins
+    // for wide outputs (qkv, fc1: 940 vs 750 TFLOP/s); for N = 768-class outputs (proj, fc2) its
+    // 256-CU rounds quantise badly (591 tiles = 2.3 rounds) and the 128x128 tiling is faster.
+    if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
+    else mode = 1;
+  }
+  static bool attr[4] = {false, false, false, false};
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
                  2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
-  hipLaunchKernelGGL((gemm_bf16_tn<EPI, ALOAD, SF32>), dim3(p.total_tiles), dim3(256), GEMM_LDS, s, p);
+  int rc;
+  if (mode == 4) {
+    constexpr int lds = wide::LDS_BYTES;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_wide<EPI, ALOAD, SF32>, lds, attr[3])) != RAJNI_OK) return rc;
+    p.tiles_n = (p.N + 255) / 256;
+    p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
+    const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
+    hipLaunchKernelGGL((wide::gemm_bf16_tn_wide<EPI, ALOAD, SF32>), dim3(grid), dim3(512), lds, s, p);
+  } else if (mode == 2) {
+    constexpr int lds = pipe::Cfg<8>::LDS_BYTES;
+    if ((rc = set_lds_attr(&pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 8>, lds, attr[0])) != RAJNI_OK) return rc;
+    p.total_tiles = t256;
+    hipLaunchKernelGGL((pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 8>), dim3(t256), dim3(256), lds, s, p);
+  } else if (mode == 3) {
+    constexpr int lds = pipe::Cfg<4>::LDS_BYTES;
+    if ((rc = set_lds_attr(&pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 4>, lds, attr[1])) != RAJNI_OK) return rc;
+    p.total_tiles = t128;
+    hipLaunchKernelGGL((pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 4>), dim3(t128), dim3(256), lds, s, p);
+  } else {
+    constexpr int lds = small::LDS_BYTES;
+    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32>, lds, attr[2])) != RAJNI_OK) return rc;
+    p.total_tiles = t128;
+    hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32>), dim3(t128), dim3(256), lds, s, p);
+  }
   RAJNI_CHECK_LAUNCH("gemm_bf16_tn");
   return RAJNI_OK;
 }
 
 }  // namespace
 
+extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
+// diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
+extern "C" void rajni_debug_set_gemm_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+
 int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   RAJNI_REQUIRE(a.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_linear: only bf16 is built");
   RAJNI_REQUIRE(a.x && a.w && a.y, RAJNI_ERR_INVALID, "rajni_linear: null pointer");
-  RAJNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, RAJNI_ERR_INVALID,
+  RAJNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 64 == 0, RAJNI_ERR_INVALID,
                 "rajni_linear: M,N>0 and K %% 64 == 0 required (M=%d N=%d K=%d)", a.M, a.N, a.K);
   RAJNI_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0, RAJNI_ERR_INVALID,
                 "rajni_linear: leading dimensions must be multiples of 8 elements");
@@ -316,8 +810,6 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   p.ridx = a.r_idx; p.r_np = a.r_np > 0 ? a.r_np : 1; p.r_nsrc = a.r_nsrc;
   p.Y = a.y; p.ldc = a.ldc;
   p.M = a.M; p.N = a.N; p.K = a.K;
-  p.tiles_n = (a.N + BN - 1) / BN;
-  p.total_tiles = p.tiles_n * ((a.M + BM - 1) / BM);
   switch (a.epilogue) {
     case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN, false>(p, KC_GEMM_BIAS, s);
     case RAJNI_EPI_BIAS_GELU: return launch_gemm<EPI_GELU, ALOAD_PLAIN, false>(p, KC_GEMM_GELU, s);
@@ -339,7 +831,7 @@ int launch_patch_embed(const void* images, const void* w, const float* bias, con
   RAJNI_REQUIRE(P >= 8 && (P & (P - 1)) == 0 && S % P == 0 && S % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_patch_embed: patch size must be a power of two >= 8 dividing the image (P=%d S=%d)", P, S);
   const int K = Cin * P * P;
-  RAJNI_REQUIRE(K % BK == 0 && C % 8 == 0, RAJNI_ERR_UNSUPPORTED,
+  RAJNI_REQUIRE(K % 64 == 0 && C % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_patch_embed: Cin*P*P %% 64 == 0 and C %% 8 == 0 required");
   int log2ps = 0;
   while ((1 << log2ps) < P) ++log2ps;
@@ -350,8 +842,6 @@ int launch_patch_embed(const void* images, const void* w, const float* bias, con
   p.bias = bias;
   p.Y = x; p.ldc = C;
   p.M = B * npatch; p.N = C; p.K = K;
-  p.tiles_n = (C + BN - 1) / BN;
-  p.total_tiles = p.tiles_n * ((p.M + BM - 1) / BM);
   p.cin = Cin; p.S = S; p.log2ps = log2ps; p.gw = gw; p.npatch = npatch;
   p.pos = (const bf16_t*)pos; p.pos_off = pos_has_cls ? 1 : 0;
   int rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librajni_hip.so")
+LIB_PATH = os.environ.get("RAJNI_HIP_LIB") or os.path.join(_HERE, "lib", "librajni_hip.so")
 
 RAJNI_F32, RAJNI_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2
@@ -71,6 +71,8 @@ _SIGS = {
     "rajni_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                 c_int, c_int, c_void_p]),
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
+    "rajni_debug_force_gemm_tiling": (None, [c_int]),
+    "rajni_debug_set_gemm_stamps": (None, [c_void_p]),
     "rajni_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rajni_vit_workspace_bytes": (c_size_t, [C.POINTER(VitPlan)]),

@@ -23,11 +23,11 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def pack_weight(w: torch.Tensor, dtype=torch.bfloat16, device=None) -> torch.Tensor:
-    """[N, K...] Linear/Conv weight -> contiguous [ceil128(N), K] in `dtype`, zero padded rows
-    (the GEMM stages whole 128-row W tiles)."""
+    """[N, K...] Linear/Conv weight -> contiguous [ceil256(N), K] in `dtype`, zero padded rows
+    (the GEMM stages whole 128- or 256-row W tiles)."""
     n = w.shape[0]
     w2 = w.detach().reshape(n, -1)
-    npad = (n + 127) // 128 * 128
+    npad = (n + 255) // 256 * 256
     out = torch.zeros((npad, w2.shape[1]), dtype=dtype, device=device if device is not None else w.device)
     out[:n].copy_(w2)
     return out

@@ -45,9 +45,18 @@ def test_device_is_gfx950():
 # GEMM + epilogues
 # ---------------------------------------------------------------------------------------------
 
+@pytest.fixture(params=[1, 2, 3, 4], ids=["t128x128x64", "t256x128x32", "t128x128x32", "t256x256x64"])
+def tiling(request):
+    """Every GEMM tiling must give the same answers: force each one (rajni_debug_force_gemm_tiling)."""
+    nat.lib().rajni_debug_force_gemm_tiling(request.param)
+    yield request.param
+    nat.lib().rajni_debug_force_gemm_tiling(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(394, 2304, 768), (256, 768, 768), (130, 3072, 768), (346, 768, 3072),
-                                   (7, 1000, 768), (64, 10, 128), (1, 192, 192), (1154, 576, 192)])
-def test_linear_bias(M, N, K):
+                                   (7, 1000, 768), (64, 10, 128), (1, 192, 192), (1154, 576, 192), (2100, 384, 64),
+                                   (513, 260, 128)])
+def test_linear_bias(M, N, K, tiling):
     rng = np.random.default_rng(M * 7 + N)
     x = bf16_round_np(rng.standard_normal((M, K), dtype=np.float32))
     w = bf16_round_np(rng.standard_normal((N, K), dtype=np.float32) * 0.05)
@@ -58,7 +67,7 @@ def test_linear_bias(M, N, K):
     close(host(y), want, what=f"linear {M}x{N}x{K}")
 
 
-def test_linear_identity_asymmetric():
+def test_linear_identity_asymmetric(tiling):
     """A = I against an ASYMMETRIC weight: catches a transposed / permuted output mapping exactly."""
     K = N = 256
     M = 256
@@ -69,7 +78,7 @@ def test_linear_identity_asymmetric():
     np.testing.assert_array_equal(host(y), w.T.astype(np.float64))
 
 
-def test_linear_gelu():
+def test_linear_gelu(tiling):
     rng = np.random.default_rng(5)
     M, N, K = 300, 512, 256
     x = bf16_round_np(rng.standard_normal((M, K), dtype=np.float32))
@@ -82,7 +91,7 @@ def test_linear_gelu():
 
 @pytest.mark.parametrize("stream_f32", [False, True])
 @pytest.mark.parametrize("gather", [False, True])
-def test_linear_resid_layerscale(gather, stream_f32):
+def test_linear_resid_layerscale(gather, stream_f32, tiling):
     rng = np.random.default_rng(9)
     B, Nsrc, Np, Cc, K = 3, 50, 37, 256, 192
     x = bf16_round_np(rng.standard_normal((B, Np if gather else Nsrc, K), dtype=np.float32))
@@ -249,7 +258,7 @@ def test_attention_online_softmax_spike():
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("S,P,Cc,B,has_cls", [(64, 16, 128, 3, True), (224, 16, 192, 2, True), (64, 16, 128, 2, False),
                                               (32, 8, 64, 5, True)])
-def test_patch_embed(S, P, Cc, B, has_cls, out_f32):
+def test_patch_embed(S, P, Cc, B, has_cls, out_f32, tiling):
     rng = np.random.default_rng(S + Cc)
     img = bf16_round_np(rng.standard_normal((B, 3, S, S), dtype=np.float32))
     w = bf16_round_np(rng.standard_normal((Cc, 3, P, P), dtype=np.float32) * 0.05)
