@@ -19,6 +19,7 @@
 //           per CU), register-double-buffered fragments, LDS reads + LDS-DMA interleaved with MFMAs;
 //   pipe<4> 128 x 128 x 32, same pipeline, wave tile 64x64 (48 KiB, 3 workgroups per CU);
 //   small   128 x 128 x 64, 2 stages, one barrier + drain per step - for M < 1024 (head, tiny batches).
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
