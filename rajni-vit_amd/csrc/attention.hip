@@ -188,6 +188,158 @@ __global__ void __launch_bounds__(AT_THREADS) attn_bf16_d64(const AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Np <= 256 (every ViT/DeiT at 224 px, and the late stages of larger models): one 8-wave workgroup
+// per (image, head) stages ALL kept K/V rows once (<= 64 KiB), each wave owns 32 query rows and
+// keeps the whole S^T row block in registers (NSUB x 16 fp32): exact softmax with ONE max per
+// query - no running max, no rescale of O, no alpha exp - i.e. about half the VALU work of the
+// online form, which is what bounds attention at these sizes (16 exp + ~110 VALU vs 8 MFMAs per
+// 32-key block).  NSUB = ceil(Np/32) is a template parameter so S stays in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATF_THREADS = 512;
+
+template <int NSUB>
+__global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NSUB * 32;
+  char* sk = smem;
+  char* sv = smem + ROWS * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5, g = lane >> 4, l15 = lane & 15;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int np = a.np, C = a.H * 64, C3 = 3 * C;
+  const bf16_t* img = a.qkv + (long)b * a.n_src * C3;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+  const int qbase = wave * 32;
+  const bool active = qbase < np;
+
+  // ---- Q fragments from HBM while K/V are staged
+  bf16x8 qf[4];
+  {
+    int q = qbase + l31;
+    if (q > np - 1) q = np - 1;
+    const int srow = idx ? idx[q] : q;
+    const bf16_t* qp = img + (long)srow * C3 + head * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  // ---- stage all K and V rows (gathered through keep_idx), zero-fill up to ROWS
+  {
+    const int st_c = tid & 7, st_r = tid >> 3;  // 64 rows per pass
+#pragma unroll
+    for (int i = 0; i < (ROWS + 63) / 64; ++i) {
+      const int t = st_r + 64 * i;
+      if (t < ROWS) {
+        uint4 kr = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
+        if (t < np) {
+          const int srow = idx ? idx[t] : t;
+          const bf16_t* rp = img + (long)srow * C3 + head * 64 + st_c * 8;
+          kr = *reinterpret_cast<const uint4*>(rp + C);
+          vr = *reinterpret_cast<const uint4*>(rp + 2 * C);
+        }
+        *reinterpret_cast<uint4*>(sk + k_off(t, st_c)) = kr;
+        *reinterpret_cast<uint4*>(sv + v_off(t, st_c)) = vr;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  // ---- S^T = K Q^T for every 32-key block
+  f32x16 s[NSUB];
+#pragma unroll
+  for (int kb = 0; kb < NSUB; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    const int krow = kb * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(krow, 2 * ks + h));
+      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+    }
+  }
+  // mask the keys past np (only in the last block)
+  {
+    const int nvalid = np - (NSUB - 1) * 32;
+    if (nvalid < 32) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kr >= nvalid) s[NSUB - 1][r] = -INFINITY;
+      }
+    }
+  }
+  // ---- exact softmax: one max per query (lane) over all registers and the other half-wave
+  float mx = s[0][0];
+#pragma unroll
+  for (int kb = 0; kb < NSUB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mc = mx * a.c;
+  float lsum = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+  for (int kb = 0; kb < NSUB; ++kb) {
+    float p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], a.c, -mc));
+      lsum += p[r];
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const u32x4 w = {pack2bf(p[8 * s2 + 0], p[8 * s2 + 1]), pack2bf(p[8 * s2 + 2], p[8 * s2 + 3]),
+                       pack2bf(p[8 * s2 + 4], p[8 * s2 + 5]), pack2bf(p[8 * s2 + 6], p[8 * s2 + 7])};
+      pb[s2] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int key0 = kb * 32 + 16 * s2 + 4 * h + (l15 >> 2);
+      const int col = 16 * (g & 1) + 4 * (l15 & 3);
+      const bf16x8 v0 = tr_pair(sv, key0, col);
+      const bf16x8 v1 = tr_pair(sv, key0, 32 + col);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb[s2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb[s2], o1, 0, 0, 0);
+    }
+  }
+  const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+  const int q = qbase + l31;
+  if (q < np) {
+    bf16_t* op = a.out + ((long)b * np + q) * C + head * 64 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint2 w0, w1;
+      w0.x = pack2bf(o0[4 * t] * inv, o0[4 * t + 1] * inv);
+      w0.y = pack2bf(o0[4 * t + 2] * inv, o0[4 * t + 3] * inv);
+      w1.x = pack2bf(o1[4 * t] * inv, o1[4 * t + 1] * inv);
+      w1.y = pack2bf(o1[4 * t + 2] * inv, o1[4 * t + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 8 * t) = w0;
+      *reinterpret_cast<uint2*>(op + 32 + 8 * t) = w1;
+    }
+  }
+}
+
+template <int NSUB>
+int launch_full(const AttnArgs& a, int B, hipStream_t s) {
+  constexpr int lds = NSUB * 32 * 128 * 2;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_d64_full<NSUB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { rajni_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e)); return RAJNI_ERR_LAUNCH; }
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bf16_d64_full<NSUB>, dim3(a.H, B), dim3(ATF_THREADS), lds, s, a);
+  return RAJNI_OK;
+}
+int g_force_attn = 0;  // 0 auto, 1 chunked online-softmax kernel, 2 full-row kernel (tests)
+
 }  // namespace
 
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
@@ -206,8 +358,26 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   const double flops = 4.0 * B * H * (double)np * np * D;
   const double bytes = 2.0 * B * (double)np * H * D * 4.0;
   ProfScope prof(KC_ATTENTION, s, flops, bytes);
-  hipLaunchKernelGGL(attn_bf16_d64, dim3((np + AT_QROWS - 1) / AT_QROWS, H, B), dim3(AT_THREADS), 0,
-                     s, a);
+  const int nsub = (np + 31) / 32;
+  if (nsub <= 8 && g_force_attn != 1) {
+    int rc = RAJNI_OK;
+    switch (nsub) {
+      case 1: rc = launch_full<1>(a, B, s); break;
+      case 2: rc = launch_full<2>(a, B, s); break;
+      case 3: rc = launch_full<3>(a, B, s); break;
+      case 4: rc = launch_full<4>(a, B, s); break;
+      case 5: rc = launch_full<5>(a, B, s); break;
+      case 6: rc = launch_full<6>(a, B, s); break;
+      case 7: rc = launch_full<7>(a, B, s); break;
+      default: rc = launch_full<8>(a, B, s); break;
+    }
+    if (rc != RAJNI_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(attn_bf16_d64, dim3((np + AT_QROWS - 1) / AT_QROWS, H, B), dim3(AT_THREADS), 0,
+                       s, a);
+  }
   RAJNI_CHECK_LAUNCH("attn_bf16_d64");
   return RAJNI_OK;
 }
+
+extern "C" void rajni_debug_force_attention(int mode) { g_force_attn = mode; }

@@ -181,3 +181,13 @@ def test_evaluate_model_on_device():
     w.to(DEV)
     correct = sum(int((w(x.to(DEV)).argmax(1).cpu() == y).sum()) for x, y in loader[:2])
     assert acc == pytest.approx(100.0 * correct / 16)
+
+
+def test_cli_synthetic_run(capsys):
+    """`python -m rajni_amd.run` equivalent on synthetic batches: prunes (B1 fixed) and reports."""
+    from rajni_amd import run
+    acc, thr = run.main(["--model", "vit_micro_patch16_64", "--batch_size", "8", "--max_batches", "2", "--warmup", "1",
+                         "--compare_base", "--synthetic"])
+    out = capsys.readouterr().out
+    assert thr > 0 and 0 <= acc <= 100
+    assert "Speedup" in out and "Token counts" in out

@@ -218,9 +218,18 @@ def test_score_select_fused(B, N, H):
 # attention
 # ---------------------------------------------------------------------------------------------
 
+@pytest.fixture(params=[1, 2], ids=["online_chunked", "full_row"])
+def attn_mode(request):
+    """Both attention kernels (np <= 256 may use either) must agree with the oracle."""
+    nat.lib().rajni_debug_force_attention(request.param)
+    yield request.param
+    nat.lib().rajni_debug_force_attention(0)
+
+
 @pytest.mark.parametrize("B,N,Np,H", [(2, 197, 173, 12), (1, 577, 404, 16), (3, 17, 13, 2), (2, 87, 87, 3),
-                                      (1, 130, 129, 1), (2, 40, 2, 2), (1, 300, 257, 2)])
-def test_attention_packed(B, N, Np, H):
+                                      (1, 130, 129, 1), (2, 40, 2, 2), (1, 300, 257, 2), (2, 256, 256, 2),
+                                      (2, 260, 225, 1), (1, 152, 121, 3), (1, 40, 33, 2)])
+def test_attention_packed(B, N, Np, H, attn_mode):
     rng = np.random.default_rng(N * 31 + Np)
     Cc = H * 64
     qkv = bf16_round_np(rng.standard_normal((B, N, 3 * Cc), dtype=np.float32))
@@ -238,7 +247,7 @@ def test_attention_packed(B, N, Np, H):
     close(host(out), want, rel=1.5e-2, what="attention")
 
 
-def test_attention_online_softmax_spike():
+def test_attention_online_softmax_spike(attn_mode):
     """Force the running-max rescale: one late key dominates (guide rule 26)."""
     rng = np.random.default_rng(3)
     B, N, H = 1, 200, 1

@@ -184,3 +184,18 @@ def test_oracle_is_not_imported_by_the_product():
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
                 assert "rajni_oracle" not in src, fn
+
+
+def test_cli_flags_match_reference_and_schedule_loader(tmp_path):
+    """rajni/run.py:17-43 flag set; JSON schedule keys become ints (B1)."""
+    from rajni_amd import run
+    a = run.get_args(["--batch_size", "32", "--model", "vit_tiny_patch16_224", "--schedule", "s.json", "--compare_base",
+                      "--max_batches", "3", "--warmup", "2", "--device", "cuda", "--num_workers", "4", "--data_path", "/x"])
+    assert (a.batch_size, a.model, a.schedule, a.compare_base, a.max_batches, a.warmup, a.device, a.num_workers,
+            a.data_path) == (32, "vit_tiny_patch16_224", "s.json", True, 3, 2, "cuda", 4, "/x")
+    d = run.get_args([])
+    assert (d.batch_size, d.warmup, d.model, d.device, d.max_batches) == (256, 5, "vit_base_patch16_224", "cuda", None)
+    f = tmp_path / "schedule.json"
+    f.write_text('{"3": {"keep_ratio": 0.95, "update": false}, "4": {"keep_ratio": 0.95}}')
+    assert run.load_schedule(str(f)) == {3: {"keep_ratio": 0.95, "update": False}, 4: {"keep_ratio": 0.95}}
+    assert run.load_schedule(None) == run.README_SCHEDULE
