@@ -8,8 +8,9 @@
  *   - the caller owns all buffers, nothing is allocated or freed inside, no host sync inside;
  *   - every launch goes to the hipStream_t given (pass torch's current stream);
  *   - returns RAJNI_OK (0) or an error code; rajni_last_error() gives a host string (thread local);
- *   - `dtype` is the activation/weight element type.  RAJNI_BF16 is the implemented compute type
- *     (fp32 accumulation everywhere); RAJNI_F32 returns RAJNI_ERR_UNSUPPORTED where not built.
+ *   - `dtype` is the activation/weight element type of the model: RAJNI_BF16 (the fast path: bf16
+ *     MFMA, fp32 accumulation) or RAJNI_F32 (accuracy path: every tensor fp32, v_mfma_f32_16x16x4_f32
+ *     GEMMs, VALU attention; ~1/16 of the bf16 MFMA rate).
  *   - activations are row-major [B, N, C]; qkv is [B, N, 3*C] with the last axis laid out
  *     [3][H][D] (timm convention; importance.py:14, attention.py:46-47);
  *   - keep_idx is int32 on the device ([B, keep+1], slot 0 = CLS = 0, rest ascending); the Python

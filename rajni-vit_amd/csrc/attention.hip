@@ -325,6 +325,89 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnA
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 model path (accuracy path: "logits within 1e-3 of the reference's fp32 run").  No MFMA: four
+// lanes share a query row (16 of the 64 head dims each), keys are staged in 64-key fp32 LDS chunks
+// (read as broadcasts), online softmax per key in fp32.  ~50x the bf16 kernel's time, by design simple.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgsF32 {
+  const float* qkv; const int* idx; float* out;
+  int n_src, np, H;
+  float c;
+};
+
+__global__ void __launch_bounds__(256) attn_f32_d64(const AttnArgsF32 a) {
+  __shared__ __attribute__((aligned(16))) float sk[64 * 64];
+  __shared__ __attribute__((aligned(16))) float sv[64 * 64];
+  const int tid = threadIdx.x;
+  const int qrow = tid >> 2, pt = tid & 3;           // 64 query rows x 4 lanes
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int np = a.np, C = a.H * 64, C3 = 3 * C;
+  const float* img = a.qkv + (long)b * a.n_src * C3;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+  int q = blockIdx.x * 64 + qrow;
+  const bool valid = q < np;
+  if (!valid) q = np - 1;
+  float qv[16], o[16];
+  {
+    const int srow = idx ? idx[q] : q;
+    const float* qp = img + (long)srow * C3 + head * 64 + pt * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = reinterpret_cast<const float4*>(qp)[j];
+      qv[4 * j] = t.x; qv[4 * j + 1] = t.y; qv[4 * j + 2] = t.z; qv[4 * j + 3] = t.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o[j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    __syncthreads();
+    // stage 64 keys x 64 dims of K and V: 1024 float4 each, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;           // float4 index
+      const int r = e >> 4, c4 = e & 15;
+      const int t = c0 + r;
+      float4 kq = make_float4(0, 0, 0, 0), vq = make_float4(0, 0, 0, 0);
+      if (t < np) {
+        const int srow = idx ? idx[t] : t;
+        const float* rp = img + (long)srow * C3 + head * 64 + c4 * 4;
+        kq = *reinterpret_cast<const float4*>(rp + C);
+        vq = *reinterpret_cast<const float4*>(rp + 2 * C);
+      }
+      reinterpret_cast<float4*>(sk)[e] = kq;
+      reinterpret_cast<float4*>(sv)[e] = vq;
+    }
+    __syncthreads();
+    const int nk = np - c0 < 64 ? np - c0 : 64;
+    for (int j = 0; j < nk; ++j) {
+      const float* kr = sk + j * 64 + pt * 16;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d = fmaf(qv[e], kr[e], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      const float sc = d * a.c;
+      const float m_new = fmaxf(m_run, sc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float pj = __builtin_amdgcn_exp2f(sc - m_new);
+      l_run = fmaf(l_run, alpha, pj);
+      m_run = m_new;
+      const float* vr = sv + j * 64 + pt * 16;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = fmaf(o[e], alpha, pj * vr[e]);
+    }
+  }
+  if (valid) {
+    const float inv = 1.0f / l_run;
+    float* op = a.out + ((long)b * np + q) * C + head * 64 + pt * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      reinterpret_cast<float4*>(op)[j] = make_float4(o[4 * j] * inv, o[4 * j + 1] * inv, o[4 * j + 2] * inv, o[4 * j + 3] * inv);
+  }
+}
+
 template <int NSUB>
 int launch_full(const AttnArgs& a, int B, hipStream_t s) {
   constexpr int lds = NSUB * 32 * 128 * 2;
@@ -343,7 +426,7 @@ int g_force_attn = 0;  // 0 auto, 1 chunked online-softmax kernel, 2 full-row ke
 }  // namespace
 
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
-                     int H, int D, float scale, hipStream_t s) {
+                     int H, int D, float scale, int dtype, hipStream_t s) {
   RAJNI_REQUIRE(qkv && out, RAJNI_ERR_INVALID, "rajni_attention: null pointer");
   RAJNI_REQUIRE(D == 64, RAJNI_ERR_UNSUPPORTED, "rajni_attention: head dim %d not built (64 only)", D);
   RAJNI_REQUIRE(B > 0 && H > 0 && np > 0 && n_src >= np, RAJNI_ERR_INVALID,
@@ -351,6 +434,16 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   RAJNI_REQUIRE(keep_idx != nullptr || np == n_src, RAJNI_ERR_INVALID,
                 "rajni_attention: identity selection needs np == n_src");
   RAJNI_REQUIRE(H <= 65535 && B <= 65535, RAJNI_ERR_UNSUPPORTED, "rajni_attention: grid too large");
+  if (dtype == RAJNI_F32) {
+    AttnArgsF32 f{};
+    f.qkv = (const float*)qkv; f.idx = keep_idx; f.out = (float*)out;
+    f.n_src = n_src; f.np = np; f.H = H; f.c = scale * 1.4426950408889634f;
+    ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)np * np * D, 4.0 * B * (double)np * H * D * 4.0);
+    hipLaunchKernelGGL(attn_f32_d64, dim3((np + 63) / 64, H, B), dim3(256), 0, s, f);
+    RAJNI_CHECK_LAUNCH("attn_f32_d64");
+    return RAJNI_OK;
+  }
+  RAJNI_REQUIRE(dtype == RAJNI_BF16, RAJNI_ERR_INVALID, "rajni_attention: bad dtype %d", dtype);
   AttnArgs a{};
   a.qkv = (const bf16_t*)qkv; a.idx = keep_idx; a.out = (bf16_t*)out;
   a.n_src = n_src; a.np = np; a.H = H;

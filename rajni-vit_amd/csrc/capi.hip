@@ -23,7 +23,7 @@ hipEvent_t get_event() {
 }
 const char* const kNames[RAJNI_NUM_KCLASS] = {
     "gemm_bf16_tn<bias>", "gemm_bf16_tn<bias,gelu>", "gemm_bf16_tn<bias,ls,resid>",
-    "gemm_bf16_tn<patch>", "attn_bf16_d64", "layernorm_bf16", "score_select_kernel<fused>",
+    "gemm_bf16_tn<patch>", "attn_bf16_d64", "layernorm_kernel", "score_select_kernel<fused>",
     "score_select_kernel<scores>", "score_select_kernel<select>", "gather_rows_kernel",
     "cls_pos_kernel", "other"};
 }  // namespace
@@ -77,33 +77,33 @@ int rajni_device_check(void) {
   return RAJNI_OK;
 }
 
-#define NEED_BF16(name)                                                                      \
-  RAJNI_REQUIRE(dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, name ": dtype %d not built (bf16 only)", dtype)
+#define NEED_DTYPE(name)                                                                     \
+  RAJNI_REQUIRE(dtype == RAJNI_BF16 || dtype == RAJNI_F32, RAJNI_ERR_INVALID, name ": bad dtype %d", dtype)
 
 int rajni_importance(const void* qkv, void* scores_out, int B, int N, int H, int D, float eps,
                      int dtype, rajni_stream_t stream) {
-  NEED_BF16("rajni_importance");
+  NEED_DTYPE("rajni_importance");
   RAJNI_REQUIRE(qkv && scores_out, RAJNI_ERR_INVALID, "rajni_importance: null pointer");
-  return launch_score_select(qkv, nullptr, B, N, H, D, eps, 0, scores_out, nullptr, nullptr,
+  return launch_score_select(qkv, nullptr, B, N, H, D, eps, 0, scores_out, nullptr, nullptr, dtype,
                              (hipStream_t)stream);
 }
 
 int rajni_select_topk(const void* scores, int B, int N, int keep, int32_t* keep_idx,
                       void* next_scores, int dtype, rajni_stream_t stream) {
-  NEED_BF16("rajni_select_topk");
+  NEED_DTYPE("rajni_select_topk");
   RAJNI_REQUIRE(scores && keep_idx, RAJNI_ERR_INVALID, "rajni_select_topk: null pointer");
   RAJNI_REQUIRE(keep >= 1, RAJNI_ERR_INVALID, "rajni_select_topk: keep must be >= 1");
-  return launch_score_select(nullptr, scores, B, N, 0, 0, 0.f, keep, nullptr, keep_idx, next_scores,
+  return launch_score_select(nullptr, scores, B, N, 0, 0, 0.f, keep, nullptr, keep_idx, next_scores, dtype,
                              (hipStream_t)stream);
 }
 
 int rajni_score_select(const void* qkv, int B, int N, int H, int D, float eps, int keep,
                        void* scores_out, int32_t* keep_idx, void* next_scores, int dtype,
                        rajni_stream_t stream) {
-  NEED_BF16("rajni_score_select");
+  NEED_DTYPE("rajni_score_select");
   RAJNI_REQUIRE(qkv && keep_idx, RAJNI_ERR_INVALID, "rajni_score_select: null pointer");
   RAJNI_REQUIRE(keep >= 1, RAJNI_ERR_INVALID, "rajni_score_select: keep must be >= 1");
-  return launch_score_select(qkv, nullptr, B, N, H, D, eps, keep, scores_out, keep_idx, next_scores,
+  return launch_score_select(qkv, nullptr, B, N, H, D, eps, keep, scores_out, keep_idx, next_scores, dtype,
                              (hipStream_t)stream);
 }
 
@@ -116,14 +116,14 @@ int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int
 
 int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                     int H, int D, float scale, int dtype, rajni_stream_t stream) {
-  NEED_BF16("rajni_attention");
-  return launch_attention(qkv, keep_idx, out, B, n_src, np, H, D, scale, (hipStream_t)stream);
+  NEED_DTYPE("rajni_attention");
+  return launch_attention(qkv, keep_idx, out, B, n_src, np, H, D, scale, dtype, (hipStream_t)stream);
 }
 
 int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,
                     int rows, int C, float eps, int dtype, int x_f32, rajni_stream_t stream) {
-  NEED_BF16("rajni_layernorm");
-  return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, x_f32, (hipStream_t)stream);
+  NEED_DTYPE("rajni_layernorm");
+  return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, x_f32, dtype, (hipStream_t)stream);
 }
 
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {
@@ -134,8 +134,8 @@ int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                       const void* pos, int pos_has_cls, void* x, int x_f32, int B, int Cin, int S,
                       int P, int C, int dtype, rajni_stream_t stream) {
-  NEED_BF16("rajni_patch_embed");
-  return launch_patch_embed(images, w, bias, cls, pos, pos_has_cls, x, x_f32, B, Cin, S, P, C,
+  NEED_DTYPE("rajni_patch_embed");
+  return launch_patch_embed(images, w, bias, cls, pos, pos_has_cls, x, x_f32, B, Cin, S, P, C, dtype,
                             (hipStream_t)stream);
 }
 

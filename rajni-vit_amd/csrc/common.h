@@ -39,6 +39,32 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// 8 consecutive elements of the activation dtype (bf16_t or float) <-> 8 floats
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* f) {
+  unpack8(*reinterpret_cast<const uint4*>(p), f);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* f) {
+  *reinterpret_cast<uint4*>(p) = pack8(f);
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+// value as the activation dtype would hold it, and scalar load/store
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -86,13 +112,13 @@ struct ProfScope {
 int launch_linear(const rajni_linear_args& a, hipStream_t s);
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                        const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
-                       int P, int C, hipStream_t s);
+                       int P, int C, int dtype, hipStream_t s);
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
-                     int C, float eps, int x_f32, hipStream_t s);
+                     int C, float eps, int x_f32, int dtype, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
-                     int H, int D, float scale, hipStream_t s);
+                     int H, int D, float scale, int dtype, hipStream_t s);
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
                         float eps, int keep, void* scores_out, int32_t* keep_idx,
-                        void* next_scores, hipStream_t s);
+                        void* next_scores, int dtype, hipStream_t s);
 int launch_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int n_src, int n_dst,
                        int row_bytes, hipStream_t s);

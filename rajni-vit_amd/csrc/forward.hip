@@ -19,7 +19,7 @@ struct Workspace {
 
 Workspace carve(const rajni_vit_plan& p) {
   const size_t gw = p.img_size / p.patch_size, n0 = gw * gw + 1;
-  const size_t rows = (size_t)p.B * n0, es = 2, xs = p.resid_bf16 ? 2 : 4;
+  const size_t rows = (size_t)p.B * n0, es = p.dtype == RAJNI_F32 ? 4 : 2, xs = (p.dtype == RAJNI_F32 || !p.resid_bf16) ? 4 : 2;
   Workspace w{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
@@ -35,7 +35,8 @@ Workspace carve(const rajni_vit_plan& p) {
 }
 
 // next_scores[b, j] = scores[b, idx[b, j]]   (attention.py:58) - used with a forced selection
-__global__ void carry_scores_kernel(const bf16_t* scores, const int* idx, bf16_t* out, int B, int N, int np) {
+template <typename T>
+__global__ void carry_scores_kernel(const T* scores, const int* idx, T* out, int B, int N, int np) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * np) return;
   const int b = i / np;
@@ -43,7 +44,7 @@ __global__ void carry_scores_kernel(const bf16_t* scores, const int* idx, bf16_t
 }
 
 int check_plan(const rajni_vit_plan& p) {
-  RAJNI_REQUIRE(p.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_vit_forward: dtype %d not built (bf16 only)", p.dtype);
+  RAJNI_REQUIRE(p.dtype == RAJNI_BF16 || p.dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_vit_forward: bad dtype %d", p.dtype);
   RAJNI_REQUIRE(p.B > 0 && p.depth > 0 && p.blocks != nullptr, RAJNI_ERR_INVALID, "rajni_vit_forward: bad plan");
   RAJNI_REQUIRE(p.C == p.H * p.D && p.D == 64, RAJNI_ERR_UNSUPPORTED,
                 "rajni_vit_forward: need C == H*D and head dim 64 (C=%d H=%d D=%d)", p.C, p.H, p.D);
@@ -77,9 +78,10 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
   const int gw = p.img_size / p.patch_size;
   int N = gw * gw + 1;
 
-  const int sf32 = p.resid_bf16 ? 0 : 1;  // residual stream element type
+  const int dt = p.dtype;
+  const int sf32 = (dt == RAJNI_BF16 && !p.resid_bf16) ? 1 : 0;  // bf16 model with an fp32 residual stream
   rc = launch_patch_embed(images, p.patch_w, p.patch_b, p.cls_token, p.pos_embed, p.pos_has_cls,
-                          w.xa, sf32, B, p.in_chans, p.img_size, p.patch_size, C, s);
+                          w.xa, sf32, B, p.in_chans, p.img_size, p.patch_size, C, dt, s);
   if (rc != RAJNI_OK) return rc;
 
   char* cur = w.xa;
@@ -91,10 +93,10 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (p.token_counts) p.token_counts[i] = N;  // model.py:43
     const int M = B * N;
     // ---- norm1 + qkv on ALL N tokens (model.py:51, attention.py:21-22)
-    rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, s);
+    rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
     rajni_linear_args g{};
-    g.dtype = RAJNI_BF16;
+    g.dtype = dt;
     g.x = w.xn; g.lda = C; g.w = blk.qkv_w; g.ldw = C; g.bias = blk.qkv_b;
     g.y = w.qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epilogue = RAJNI_EPI_BIAS;
     rc = launch_linear(g, s);
@@ -111,22 +113,26 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
         const void* full = carried;
         if (recompute) {
           void* dst = blk.scores ? blk.scores : (void*)w.scf;
-          rc = launch_score_select(w.qkv, nullptr, B, N, p.H, p.D, 1e-6f, 0, dst, nullptr, nullptr, s);
+          rc = launch_score_select(w.qkv, nullptr, B, N, p.H, p.D, 1e-6f, 0, dst, nullptr, nullptr, dt, s);
           if (rc != RAJNI_OK) return rc;
           full = dst;
         }
         const int n = B * Np;
-        hipLaunchKernelGGL(carry_scores_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-                           (const bf16_t*)full, blk.forced_keep_idx, (bf16_t*)blk.next_scores, B, N, Np);
+        if (dt == RAJNI_F32)
+          hipLaunchKernelGGL(carry_scores_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s,
+                             (const float*)full, blk.forced_keep_idx, (float*)blk.next_scores, B, N, Np);
+        else
+          hipLaunchKernelGGL(carry_scores_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s,
+                             (const bf16_t*)full, blk.forced_keep_idx, (bf16_t*)blk.next_scores, B, N, Np);
         RAJNI_CHECK_LAUNCH("carry_scores_kernel");
         idx = blk.forced_keep_idx;
       } else {
         if (recompute)
           rc = launch_score_select(w.qkv, nullptr, B, N, p.H, p.D, 1e-6f, blk.keep, blk.scores,
-                                   blk.keep_idx, blk.next_scores, s);
+                                   blk.keep_idx, blk.next_scores, dt, s);
         else
           rc = launch_score_select(nullptr, carried, B, N, 0, 0, 0.f, blk.keep, nullptr,
-                                   blk.keep_idx, blk.next_scores, s);
+                                   blk.keep_idx, blk.next_scores, dt, s);
         if (rc != RAJNI_OK) return rc;
         idx = blk.keep_idx;
       }
@@ -136,13 +142,13 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     }
 
     // ---- attention on the kept tokens, gather fused (attention.py:42-54)
-    rc = launch_attention(w.qkv, idx, w.att, B, N, Np, p.H, p.D, p.attn_scale, s);
+    rc = launch_attention(w.qkv, idx, w.att, B, N, Np, p.H, p.D, p.attn_scale, dt, s);
     if (rc != RAJNI_OK) return rc;
 
     // ---- proj + (gathered) residual + LayerScale (attention.py:55-56, model.py:55-58)
     const int Mp = B * Np;
     g = rajni_linear_args{};
-    g.dtype = RAJNI_BF16;
+    g.dtype = dt;
     g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1;
     g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     if (idx) {
@@ -158,16 +164,16 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     N = Np;
 
     // ---- MLP (model.py:59): norm2 -> fc1 + GELU -> fc2 + LayerScale + residual (in place)
-    rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, s);
+    rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
-    g.dtype = RAJNI_BF16;
+    g.dtype = dt;
     g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b;
     g.y = w.hid; g.ldc = p.hidden; g.M = Mp; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
-    g.dtype = RAJNI_BF16;
+    g.dtype = dt;
     g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2;
     g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = Mp; g.N = C; g.K = p.hidden;
     g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
@@ -176,10 +182,10 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
   }
 
   // ---- final norm on the CLS rows only (LN is per token; model.py:65-66) + head
-  rc = launch_layernorm(cur, (long)N * C, p.norm_w, p.norm_b, w.clsn, B, C, p.ln_eps, sf32, s);
+  rc = launch_layernorm(cur, (long)N * C, p.norm_w, p.norm_b, w.clsn, B, C, p.ln_eps, sf32, dt, s);
   if (rc != RAJNI_OK) return rc;
   rajni_linear_args g{};
-  g.dtype = RAJNI_BF16;
+  g.dtype = dt;
   g.x = w.clsn; g.lda = C; g.w = p.head_w; g.ldw = C; g.bias = p.head_b;
   const int ld = p.logits_ld > 0 ? p.logits_ld : p.num_classes;
   RAJNI_REQUIRE(ld % 8 == 0 && ld >= p.num_classes, RAJNI_ERR_INVALID,

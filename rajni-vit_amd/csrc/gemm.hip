@@ -29,8 +29,8 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
 enum { ALOAD_PLAIN = 0, ALOAD_PATCH = 1 };
 
 struct GemmParams {
-  const bf16_t* X; long lda;
-  const bf16_t* W; long ldw;
+  const void* X; long lda;      // activations (bf16, or fp32 on the fp32 model path)
+  const void* W; long ldw;      // weights, same element type
   const float* bias;
   const float* gamma;
   const void* R; long ldr;      // residual stream rows (bf16 or fp32, see SF32)
@@ -40,7 +40,7 @@ struct GemmParams {
   int tiles_n, total_tiles;
   // patch-embed A loader / epilogue
   int cin, S, log2ps, gw, npatch;
-  const bf16_t* pos; int pos_off;
+  const void* pos; int pos_off; // pos-embed rows, activation dtype
   unsigned long long* stamps;   // diagnostic builds only (RAJNI_GEMM_STAMPS): 4 s_memtime values per block
 };
 
@@ -134,7 +134,7 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb,
   } else if (EPI == EPI_PATCH) {
     const int b = m / p.npatch, pp = m - b * p.npatch;
     orow = (long)b * (p.npatch + 1) + 1 + pp;
-    const bf16_t* pr = p.pos + (long)(pp + p.pos_off) * p.ldc + nb;
+    const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.pos) + (long)(pp + p.pos_off) * p.ldc + nb;
     if (nb + 16 <= p.N) {
       float pf[16];
       unpack8(*reinterpret_cast<const uint4*>(pr), pf);
@@ -165,23 +165,25 @@ __device__ __forceinline__ int xcd_tile_of(int v, int total) {
 }
 __device__ __forceinline__ int xcd_tile(int total) { return xcd_tile_of(blockIdx.x, total); }
 
-// global source of the 16-byte chunk (row m, K offset k..k+7) of the X operand
-template <int ALOAD>
+// global source of the 16-byte chunk (row m, K offset k..) of the X operand; ET = element type
+template <int ALOAD, typename ET = bf16_t>
 struct XSource {
-  const bf16_t* base;  // PLAIN: row pointer (+ swizzled chunk); PATCH: patch origin in the image
-  int kofs;            // PATCH: this lane's k offset inside a K step
+  static constexpr int CH = 16 / (int)sizeof(ET);   // elements per 16-byte chunk
+  const ET* base;  // PLAIN: row pointer (+ swizzled chunk); PATCH: patch origin in the image
+  int kofs;        // PATCH: this lane's k offset inside a K step
   __device__ __forceinline__ void init(const GemmParams& p, int m, int chunk) {
+    const ET* X = reinterpret_cast<const ET*>(p.X);
     if (ALOAD == ALOAD_PLAIN) {
-      base = p.X + (long)m * p.lda + chunk * 8;
+      base = X + (long)m * p.lda + chunk * CH;
       kofs = 0;
     } else {
       const int b = m / p.npatch, pp = m - b * p.npatch;
       const int py = pp / p.gw, px = pp - py * p.gw;
-      base = p.X + ((long)b * p.cin * p.S + (py << p.log2ps)) * p.S + (px << p.log2ps);
-      kofs = chunk * 8;
+      base = X + ((long)b * p.cin * p.S + (py << p.log2ps)) * p.S + (px << p.log2ps);
+      kofs = chunk * CH;
     }
   }
-  __device__ __forceinline__ const bf16_t* at(const GemmParams& p, int k0) const {
+  __device__ __forceinline__ const ET* at(const GemmParams& p, int k0) const {
     if (ALOAD == ALOAD_PLAIN) return base + k0;
     const int k = k0 + kofs, ps2 = 2 * p.log2ps;
     const int ch = k >> ps2, rem = k & ((1 << ps2) - 1);
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wave * 2 + i) * 16 + r_in;
-    ws[i] = p.W + (long)(n0 + row) * p.ldw + (pos ^ key_w(row)) * 8;  // W rows padded to 128
+    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pos ^ key_w(row)) * 8;  // W rows padded to 128
   }
   auto stage = [&](int kt, int st) {
     char* sx = smem + st * C::STAGE_BYTES;
@@ -455,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) 
       int m = tm * BM + row;
       if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
       xs[i].init(p, m, pch ^ key_x(row));
-      ws[i] = p.W + (long)(tn * BN + row) * p.ldw + (pch ^ key_w(row)) * 8;  // W rows padded to 256
+      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * BN + row) * p.ldw + (pch ^ key_w(row)) * 8;  // W rows padded to 256
     }
   };
   auto stage = [&](int kt, int st) {
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     xs[i].init(p, m, pch ^ key_x(row));
-    ws[i] = p.W + (long)(n0 + row) * p.ldw + (pch ^ key_w(row)) * 8;
+    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ key_w(row)) * 8;
   }
   auto stage = [&](int kt, int buf) {
     char* sx = smem + buf * STAGE_BYTES;
@@ -707,22 +709,6 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
 }
 }  // namespace small
 
-// x[b,0,:] = cls + pos[0]  (or cls alone when pos has no CLS row)
-template <bool SF32>
-__global__ void cls_pos_kernel(const bf16_t* cls, const bf16_t* pos, int pos_has_cls, void* x,
-                               long img_stride, int B, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  float v = bf2f(cls[c]);
-  if (pos_has_cls) v += bf2f(pos[c]);
-  store1<SF32>(x, (long)b * img_stride + c, v);
-}
-
-unsigned long long* g_stamps = nullptr;
-int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
-int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64 (tests)
-
 template <typename K>
 int set_lds_attr(K kernel, int lds, bool& done) {
   if (done) return RAJNI_OK;
@@ -735,6 +721,184 @@ int set_lds_attr(K kernel, int lds, bool& done) {
   done = true;
   return RAJNI_OK;
 }
+
+// =============================================================================================
+// fp32 model path: 128 x 128 x 32(fp32) tile - byte-for-byte the LDS geometry of the small bf16
+// tiling (128-byte rows, same swizzle keys, same LDS-DMA staging) - with v_mfma_f32_16x16x4_f32
+// (exact fp32 FMA chain, 1/16 of the bf16 rate).  A lane reads 16 bytes = 4 consecutive k of its
+// row for BOTH operands and feeds them to 4 MFMAs, element t of every lane group g covering
+// k = 4*(4*ks+g)+t: the k order inside a K step is permuted identically for X and W, so the sum is
+// the same.  All tensors (x, w, resid, pos, y) are fp32.
+// =============================================================================================
+namespace f32 {
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_BYTES = BM * BK * 4;
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+using small::key_w;
+using small::key_x;
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_row_f32(const GemmParams& p, int m, int nb, float* v, const float* gam) {
+  long orow = m;
+  if (EPI == EPI_GELU) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+  } else if (EPI == EPI_RESID) {
+    long rrow = m;
+    if (p.ridx != nullptr) {
+      const int b = m / p.r_np;
+      rrow = (long)b * p.r_nsrc + p.ridx[m];
+    }
+    const long roff = rrow * p.ldr + nb;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], reinterpret_cast<const float*>(p.R)[roff + j]);
+  } else if (EPI == EPI_PATCH) {
+    const int b = m / p.npatch, pp = m - b * p.npatch;
+    orow = (long)b * (p.npatch + 1) + 1 + pp;
+    const float* pr = reinterpret_cast<const float*>(p.pos) + (long)(pp + p.pos_off) * p.ldc + nb;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (nb + j < p.N) v[j] += pr[j];
+  }
+  const long yoff = orow * p.ldc + nb;
+  if (nb + 16 <= p.N) {
+    store16<true>(p.Y, yoff, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (nb + j < p.N) reinterpret_cast<float*>(p.Y)[yoff + j] = v[j];
+  }
+}
+
+template <int EPI, int ALOAD>
+__global__ void __launch_bounds__(256, 2) gemm_f32_tn_128x128(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_tile(p.total_tiles);
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* W = reinterpret_cast<const float*>(p.W);
+
+  const int r_in = lane >> 3, pch = lane & 7;
+  XSource<ALOAD, float> xs[4];
+  const float* ws[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + r_in;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    xs[i].init(p, m, pch ^ key_x(row));
+    ws[i] = W + (long)(n0 + row) * p.ldw + (pch ^ key_w(row)) * 4;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* sx = smem + buf * STAGE_BYTES;
+    char* sw = sx + TILE_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  int xoff[4], xkey[4], woff[4], wkey[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = wm * 64 + i * 16 + l15;
+    xoff[i] = xr * 128; xkey[i] = key_x(xr);
+    const int wr = wn * 64 + 16 * (l15 >> 2) + i * 4 + (l15 & 3);
+    woff[i] = wr * 128; wkey[i] = key_w(wr);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* sx = smem + (kt & 1) * STAGE_BYTES;
+    const char* sw = sx + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + g;
+      f32x4 xf[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[i] = *reinterpret_cast<const f32x4*>(sx + xoff[i] + ((c ^ xkey[i]) << 4));
+        wf[i] = *reinterpret_cast<const f32x4*>(sw + woff[i] + ((c ^ wkey[i]) << 4));
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][tt], xf[mi][tt], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  const int nb = n0 + wn * 64 + 16 * g;
+  float bias[16], gam[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = nb + j;
+    bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + l15;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+    epilogue_row_f32<EPI>(p, m, nb, v, gam);
+  }
+}
+
+template <int EPI, int ALOAD>
+int launch(GemmParams p, int kclass, hipStream_t s) {
+  static bool attr = false;
+  p.tiles_n = (p.N + 127) / 128;
+  p.total_tiles = p.tiles_n * ((p.M + 127) / 128);
+  int rc = set_lds_attr(&gemm_f32_tn_128x128<EPI, ALOAD>, LDS_BYTES, attr);
+  if (rc != RAJNI_OK) return rc;
+  ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
+                 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
+  hipLaunchKernelGGL((gemm_f32_tn_128x128<EPI, ALOAD>), dim3(p.total_tiles), dim3(256), LDS_BYTES, s, p);
+  RAJNI_CHECK_LAUNCH("gemm_f32_tn");
+  return RAJNI_OK;
+}
+}  // namespace f32
+
+// x[b,0,:] = cls + pos[0]  (or cls alone when pos has no CLS row)
+template <bool SF32, typename T>
+__global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void* x,
+                               long img_stride, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float v = ld1(cls + c);
+  if (pos_has_cls) v += ld1(pos + c);
+  store1<SF32>(x, (long)b * img_stride + c, v);
+}
+
+unsigned long long* g_stamps = nullptr;
+int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
+int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64 (tests)
 
 // rounds of workgroups a launch needs on 256 CUs at `per_cu` resident workgroups each, weighted by
 // the tile's relative duration: picks the tiling that finishes first
@@ -795,7 +959,7 @@ extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode;
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
 
 int launch_linear(const rajni_linear_args& a, hipStream_t s) {
-  RAJNI_REQUIRE(a.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_linear: only bf16 is built");
+  RAJNI_REQUIRE(a.dtype == RAJNI_BF16 || a.dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_linear: bad dtype %d", a.dtype);
   RAJNI_REQUIRE(a.x && a.w && a.y, RAJNI_ERR_INVALID, "rajni_linear: null pointer");
   RAJNI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 64 == 0, RAJNI_ERR_INVALID,
                 "rajni_linear: M,N>0 and K %% 64 == 0 required (M=%d N=%d K=%d)", a.M, a.N, a.K);
@@ -804,13 +968,25 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   RAJNI_REQUIRE(((uintptr_t)a.x | (uintptr_t)a.w | (uintptr_t)a.y | (uintptr_t)a.resid) % 16 == 0,
                 RAJNI_ERR_INVALID, "rajni_linear: pointers must be 16-byte aligned");
   GemmParams p{};
-  p.X = (const bf16_t*)a.x; p.lda = a.lda;
-  p.W = (const bf16_t*)a.w; p.ldw = a.ldw;
+  p.X = a.x; p.lda = a.lda;
+  p.W = a.w; p.ldw = a.ldw;
   p.bias = a.bias; p.gamma = a.gamma;
   p.R = a.resid; p.ldr = a.ldr;
   p.ridx = a.r_idx; p.r_np = a.r_np > 0 ? a.r_np : 1; p.r_nsrc = a.r_nsrc;
   p.Y = a.y; p.ldc = a.ldc;
   p.M = a.M; p.N = a.N; p.K = a.K;
+  if (a.dtype == RAJNI_F32) {
+    switch (a.epilogue) {
+      case RAJNI_EPI_BIAS: return f32::launch<EPI_BIAS, ALOAD_PLAIN>(p, KC_GEMM_BIAS, s);
+      case RAJNI_EPI_BIAS_GELU: return f32::launch<EPI_GELU, ALOAD_PLAIN>(p, KC_GEMM_GELU, s);
+      case RAJNI_EPI_BIAS_RESID:
+        RAJNI_REQUIRE(a.resid != nullptr, RAJNI_ERR_INVALID, "rajni_linear: RESID epilogue needs resid");
+        return f32::launch<EPI_RESID, ALOAD_PLAIN>(p, KC_GEMM_RESID, s);
+      default:
+        rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
+        return RAJNI_ERR_INVALID;
+    }
+  }
   switch (a.epilogue) {
     case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN, false>(p, KC_GEMM_BIAS, s);
     case RAJNI_EPI_BIAS_GELU: return launch_gemm<EPI_GELU, ALOAD_PLAIN, false>(p, KC_GEMM_GELU, s);
@@ -827,36 +1003,44 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
 
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                        const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
-                       int P, int C, hipStream_t s) {
+                       int P, int C, int dtype, hipStream_t s) {
   RAJNI_REQUIRE(images && w && cls && pos && x, RAJNI_ERR_INVALID, "rajni_patch_embed: null pointer");
   RAJNI_REQUIRE(P >= 8 && (P & (P - 1)) == 0 && S % P == 0 && S % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_patch_embed: patch size must be a power of two >= 8 dividing the image (P=%d S=%d)", P, S);
   const int K = Cin * P * P;
   RAJNI_REQUIRE(K % 64 == 0 && C % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_patch_embed: Cin*P*P %% 64 == 0 and C %% 8 == 0 required");
+  RAJNI_REQUIRE(dtype == RAJNI_BF16 || dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_patch_embed: bad dtype %d", dtype);
   int log2ps = 0;
   while ((1 << log2ps) < P) ++log2ps;
   const int gw = S / P, npatch = gw * gw;
   GemmParams p{};
-  p.X = (const bf16_t*)images; p.lda = 0;
-  p.W = (const bf16_t*)w; p.ldw = K;
+  p.X = images; p.lda = 0;
+  p.W = w; p.ldw = K;
   p.bias = bias;
   p.Y = x; p.ldc = C;
   p.M = B * npatch; p.N = C; p.K = K;
   p.cin = Cin; p.S = S; p.log2ps = log2ps; p.gw = gw; p.npatch = npatch;
-  p.pos = (const bf16_t*)pos; p.pos_off = pos_has_cls ? 1 : 0;
-  int rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)
-                   : launch_gemm<EPI_PATCH, ALOAD_PATCH, false>(p, KC_GEMM_PATCH, s);
+  p.pos = pos; p.pos_off = pos_has_cls ? 1 : 0;
+  int rc;
+  if (dtype == RAJNI_F32) rc = f32::launch<EPI_PATCH, ALOAD_PATCH>(p, KC_GEMM_PATCH, s);
+  else rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)
+                    : launch_gemm<EPI_PATCH, ALOAD_PATCH, false>(p, KC_GEMM_PATCH, s);
   if (rc != RAJNI_OK) return rc;
   {
     ProfScope prof(KC_CLS_POS, s, 0.0, 6.0 * B * C);
     const int n = B * C;
-    if (out_f32)
-      hipLaunchKernelGGL(cls_pos_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)cls,
-                         (const bf16_t*)pos, pos_has_cls, x, (long)(npatch + 1) * C, B, C);
+    const dim3 grid((n + 255) / 256), block(256);
+    const long stride = (long)(npatch + 1) * C;
+    if (dtype == RAJNI_F32)
+      hipLaunchKernelGGL((cls_pos_kernel<true, float>), grid, block, 0, s, (const float*)cls, (const float*)pos,
+                         pos_has_cls, x, stride, B, C);
+    else if (out_f32)
+      hipLaunchKernelGGL((cls_pos_kernel<true, bf16_t>), grid, block, 0, s, (const bf16_t*)cls, (const bf16_t*)pos,
+                         pos_has_cls, x, stride, B, C);
     else
-      hipLaunchKernelGGL(cls_pos_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)cls,
-                         (const bf16_t*)pos, pos_has_cls, x, (long)(npatch + 1) * C, B, C);
+      hipLaunchKernelGGL((cls_pos_kernel<false, bf16_t>), grid, block, 0, s, (const bf16_t*)cls, (const bf16_t*)pos,
+                         pos_has_cls, x, stride, B, C);
     RAJNI_CHECK_LAUNCH("cls_pos_kernel");
   }
   return RAJNI_OK;

@@ -6,30 +6,23 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 4;  // 16-byte chunks per lane: C <= 64*8*4 = 2048
 
-template <bool XF32>
-__global__ void __launch_bounds__(256) layernorm_bf16(const void* __restrict__ xv, long xs,
-                                                      const float* __restrict__ w,
-                                                      const float* __restrict__ b,
-                                                      bf16_t* __restrict__ y, int rows, int C,
-                                                      float eps) {
+template <typename TX, typename TY>
+__global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x, long xs,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        TY* __restrict__ y, int rows, int C, float eps) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const int nchunk = C >> 3;
+  const TX* xr = x + (long)row * xs;
   float v[LN_MAX_CHUNKS][8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
-      if (XF32) {
-        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xv) + (long)row * xs + c * 8);
-        const float4 a = q[0], d = q[1];
-        v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
-        v[i][4] = d.x; v[i][5] = d.y; v[i][6] = d.z; v[i][7] = d.w;
-      } else {
-        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(xv) + (long)row * xs + c * 8), v[i]);
-      }
+      load8<TX>(xr + c * 8, v[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) sum += v[i][j];
     }
@@ -48,21 +41,17 @@ __global__ void __launch_bounds__(256) layernorm_bf16(const void* __restrict__ x
     }
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-  bf16_t* yr = y + (long)row * C;
+  TY* yr = y + (long)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
-      const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
-      const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      float o[8];
+      float wv[8], bv[8], o[8];
+      load8<float>(w + c * 8, wv);
+      load8<float>(b + c * 8, bv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fmaf((v[i][j] - mean) * rstd, wv[j], bv[j]);
-      *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+      store8<TY>(yr + c * 8, o);
     }
   }
 }
@@ -86,18 +75,20 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const uint4* __restric
 }  // namespace
 
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
-                     int C, float eps, int x_f32, hipStream_t s) {
+                     int C, float eps, int x_f32, int dtype, hipStream_t s) {
   RAJNI_REQUIRE(x && w && b && y, RAJNI_ERR_INVALID, "rajni_layernorm: null pointer");
   RAJNI_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS && xs % 8 == 0,
                 RAJNI_ERR_UNSUPPORTED, "rajni_layernorm: need C %% 8 == 0, C <= 2048, stride %% 8 == 0 (C=%d)", C);
-  ProfScope prof(KC_LAYERNORM, s, 8.0 * rows * C, (x_f32 ? 6.0 : 4.0) * rows * C);
-  if (x_f32)
-    hipLaunchKernelGGL(layernorm_bf16<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, w, b,
-                       (bf16_t*)y, rows, C, eps);
+  const bool f32io = dtype == RAJNI_F32;
+  ProfScope prof(KC_LAYERNORM, s, 8.0 * rows * C, (f32io ? 8.0 : (x_f32 ? 6.0 : 4.0)) * rows * C);
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (f32io)
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, xs, w, b, (float*)y, rows, C, eps);
+  else if (x_f32)
+    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, xs, w, b, (bf16_t*)y, rows, C, eps);
   else
-    hipLaunchKernelGGL(layernorm_bf16<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, xs, w, b,
-                       (bf16_t*)y, rows, C, eps);
-  RAJNI_CHECK_LAUNCH("layernorm_bf16");
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (bf16_t*)y, rows, C, eps);
+  RAJNI_CHECK_LAUNCH("layernorm_kernel");
   return RAJNI_OK;
 }
 

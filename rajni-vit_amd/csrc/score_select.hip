@@ -16,20 +16,20 @@ namespace {
 
 constexpr int SS_THREADS = 512;
 
-struct ScoreArgs {
-  const bf16_t* qkv;        // [B,N,3C] or null (select-only)
-  const bf16_t* scores_in;  // [B,N] (select-only)
+struct ScoreArgs {          // T = activation dtype (bf16_t or float)
+  const void* qkv;          // T [B,N,3C] or null (select-only)
+  const void* scores_in;    // T [B,N] (select-only)
   int N, H, D;
   float eps;
   int keep;                 // 0: scores only
-  bf16_t* scores_out;       // [B,N] or null
+  void* scores_out;         // T [B,N] or null
   int* keep_idx;            // [B,keep+1]
-  bf16_t* next_scores;      // [B,keep+1] or null
+  void* next_scores;        // T [B,keep+1] or null
 };
 
 __device__ __forceinline__ float rank_key(float s) { return (s != s) ? INFINITY : s; }
 
-template <bool COMPUTE>
+template <bool COMPUTE, typename T>
 __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   int* wcount = reinterpret_cast<int*>(misc + 16);  // [8]
 
   if (COMPUTE) {
-    const bf16_t* base = a.qkv + (long)b * N * 3 * C;
+    const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * N * 3 * C;
     const int LP = D >> 3;             // lanes per 2*D-byte head row
     const int sub = tid & (LP - 1);
     const int grp = tid / LP, ngrp = SS_THREADS / LP;
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     // ---- CLS query row -> LDS (importance.py:18)
     for (int c = tid; c < (C >> 3); c += SS_THREADS) {
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(base + c * 8), f);
+      load8<T>(base + c * 8, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) qcls[c * 8 + j] = f[j];
     }
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     for (int pair = grp; pair < N * H; pair += ngrp) {
       const int n = pair / H, h = pair - n * H;
       float kf[8];
-      unpack8(*reinterpret_cast<const uint4*>(base + (long)n * 3 * C + C + h * D + sub * 8), kf);
+      load8<T>(base + (long)n * 3 * C + C + h * D + sub * 8, kf);
       const float* qh = qcls + h * D + sub * 8;
       float dot = 0.f;
 #pragma unroll
@@ -99,10 +99,10 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     const float inv_h = 1.0f / (float)H;
     for (int n = grp; n < N; n += ngrp) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const bf16_t* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
+      const T* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
       for (int h = 0; h < H; ++h) {
         float vf[8];
-        unpack8(*reinterpret_cast<const uint4*>(vp + h * D), vf);
+        load8<T>(vp + h * D, vf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += vf[j];
       }
@@ -162,14 +162,14 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       for (int n = tid; n < N; n += SS_THREADS) {
         const float z = (sc[n] - mu) / sd;
         const float sig = 1.0f / (1.0f + __expf(-z));
-        const bf16_t sb = f2bf(acls[n] * sig);
-        if (a.scores_out != nullptr) a.scores_out[(long)b * N + n] = sb;
-        sc[n] = bf2f(sb);
+        const float sv = round_to<T>(acls[n] * sig);   // what the reference returns: qkv's dtype
+        if (a.scores_out != nullptr) st1(reinterpret_cast<T*>(a.scores_out) + (long)b * N + n, sv);
+        sc[n] = sv;
       }
     }
     __syncthreads();
   } else {
-    for (int n = tid; n < N; n += SS_THREADS) sc[n] = bf2f(a.scores_in[(long)b * N + n]);
+    for (int n = tid; n < N; n += SS_THREADS) sc[n] = ld1(reinterpret_cast<const T*>(a.scores_in) + (long)b * N + n);
     __syncthreads();
   }
 
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   //      (attention.py:34-39: topk -> sort -> +1 -> prepend CLS; attention.py:58: carried scores)
   const int keep = a.keep;
   int* kout = a.keep_idx + (long)b * (keep + 1);
-  bf16_t* nout = a.next_scores ? a.next_scores + (long)b * (keep + 1) : nullptr;
+  T* nout = a.next_scores ? reinterpret_cast<T*>(a.next_scores) + (long)b * (keep + 1) : nullptr;
   int running = 0;
   for (int base_i = 1; base_i < N; base_i += SS_THREADS) {
     const int i = base_i + tid;
@@ -209,14 +209,14 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     if (kept) {
       const int pos = running + prefix + __popcll(bal & ((1ull << lane) - 1ull));
       kout[1 + pos] = i;
-      if (nout) nout[1 + pos] = f2bf(si);
+      if (nout) st1(nout + 1 + pos, si);
     }
     running += total;
     __syncthreads();
   }
   if (tid == 0) {
     kout[0] = 0;
-    if (nout) nout[0] = f2bf(sc[0]);
+    if (nout) st1(nout, sc[0]);
   }
 }
 
@@ -231,30 +231,34 @@ size_t ss_lds_bytes(int N, int H, int D) {
 // qkv != null: compute scores (and select when keep > 0); qkv == null: select from scores_in.
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
                         float eps, int keep, void* scores_out, int32_t* keep_idx,
-                        void* next_scores, hipStream_t s) {
+                        void* next_scores, int dtype, hipStream_t s) {
+  RAJNI_REQUIRE(dtype == RAJNI_BF16 || dtype == RAJNI_F32, RAJNI_ERR_INVALID, "score/select: bad dtype %d", dtype);
   RAJNI_REQUIRE(B > 0 && N >= 2, RAJNI_ERR_INVALID, "score/select: need B > 0 and N >= 2 (B=%d N=%d)", B, N);
   RAJNI_REQUIRE(keep >= 0 && keep <= N - 1, RAJNI_ERR_INVALID,
                 "score/select: keep=%d out of range for N=%d (keep_ratio must be <= 1)", keep, N);
   RAJNI_REQUIRE(keep == 0 || keep_idx != nullptr, RAJNI_ERR_INVALID, "score/select: keep_idx is null");
   ScoreArgs a{};
   a.N = N; a.keep = keep; a.eps = eps;
-  a.scores_out = (bf16_t*)scores_out; a.keep_idx = keep_idx; a.next_scores = (bf16_t*)next_scores;
+  a.scores_out = scores_out; a.keep_idx = keep_idx; a.next_scores = next_scores;
   size_t lds;
   if (qkv != nullptr) {
     RAJNI_REQUIRE(D == 32 || D == 64 || D == 128, RAJNI_ERR_UNSUPPORTED,
                   "importance: head dim %d not supported (32/64/128)", D);
     RAJNI_REQUIRE(H > 0, RAJNI_ERR_INVALID, "importance: H must be positive");
-    a.qkv = (const bf16_t*)qkv; a.H = H; a.D = D;
+    a.qkv = qkv; a.H = H; a.D = D;
     lds = ss_lds_bytes(N, H, D);
   } else {
     RAJNI_REQUIRE(scores_in != nullptr, RAJNI_ERR_INVALID, "select: scores is null");
-    a.scores_in = (const bf16_t*)scores_in; a.H = 1; a.D = 32;
+    a.scores_in = scores_in; a.H = 1; a.D = 32;
     lds = ss_lds_bytes(N, 1, 32);
   }
   RAJNI_REQUIRE(lds <= 160 * 1024, RAJNI_ERR_UNSUPPORTED,
                 "score/select: N=%d H=%d D=%d needs %zu B of LDS (> 160 KiB)", N, H, D, lds);
-  const void* fn = qkv ? reinterpret_cast<const void*>(&score_select_kernel<true>)
-                       : reinterpret_cast<const void*>(&score_select_kernel<false>);
+  const bool f32 = dtype == RAJNI_F32;
+  const void* fn = qkv ? (f32 ? reinterpret_cast<const void*>(&score_select_kernel<true, float>)
+                              : reinterpret_cast<const void*>(&score_select_kernel<true, bf16_t>))
+                       : (f32 ? reinterpret_cast<const void*>(&score_select_kernel<false, float>)
+                              : reinterpret_cast<const void*>(&score_select_kernel<false, bf16_t>));
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -262,12 +266,16 @@ int launch_score_select(const void* qkv, const void* scores_in, int B, int N, in
       return RAJNI_ERR_LAUNCH;
     }
   }
-  const double bytes = qkv ? (2.0 * N * H * D + H * D) * 2.0 * B + 4.0 * N * B : 6.0 * N * B;
+  const double es = f32 ? 4.0 : 2.0;
+  const double bytes = qkv ? (2.0 * N * H * D + H * D) * es * B + 4.0 * N * B : 6.0 * N * B;
   ProfScope prof(qkv ? (keep > 0 ? KC_SCORE_SELECT : KC_IMPORTANCE) : KC_SELECT, s, 0.0, bytes);
-  if (qkv)
-    hipLaunchKernelGGL(score_select_kernel<true>, dim3(B), dim3(SS_THREADS), lds, s, a);
-  else
-    hipLaunchKernelGGL(score_select_kernel<false>, dim3(B), dim3(SS_THREADS), lds, s, a);
+  if (qkv) {
+    if (f32) hipLaunchKernelGGL((score_select_kernel<true, float>), dim3(B), dim3(SS_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((score_select_kernel<true, bf16_t>), dim3(B), dim3(SS_THREADS), lds, s, a);
+  } else {
+    if (f32) hipLaunchKernelGGL((score_select_kernel<false, float>), dim3(B), dim3(SS_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((score_select_kernel<false, bf16_t>), dim3(B), dim3(SS_THREADS), lds, s, a);
+  }
   RAJNI_CHECK_LAUNCH("score_select_kernel");
   return RAJNI_OK;
 }
