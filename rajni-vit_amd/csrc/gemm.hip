@@ -403,15 +403,23 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) 
 }  // namespace pipe
 
 // =============================================================================================
-// wide tiling: 256(M) x 256(N) x 64(K), 8 waves (2 x 4) each owning 128 x 64, 2 LDS stages = 128 KiB,
-// one workgroup per CU.  Measured on the chip (tools/mfma_probe.hip, profiles/): the 128-wide tilings
-// are bound by the CU's load path (bytes staged per FLOP), not by MFMA issue or LDS; this tile stages
-// 16 KiB per 2.1 MFLOP (the 128x128 tile: 32 KiB) in full 128-byte lines.
-// K step kt (stage s = kt&1), registers holding the ks=0 fragments of tile kt on entry:
-//   half 1: MFMAs(kt,ks0)  ||  LDS reads of (kt,ks1)
-//   s_waitcnt lgkmcnt(0) vmcnt(0) ; s_barrier      -> stage s is free, tile kt+1 (stage s^1) has landed
-//   half 2: MFMAs(kt,ks1)  ||  LDS reads of (kt+1,ks0)  ||  LDS-DMA of tile kt+2 into stage s
-// One barrier per 64 MFMAs per wave; every LDS read and DMA issue sits between MFMAs.
+// stream tilings: 256(M) x BN x 64(K), 8 waves, ONE persistent workgroup per CU that walks its tiles
+// as one continuous stream of K steps.  Measured on the chip (tools/mfma_probe.hip, tools/
+// gemm_stamps.py, PMC runs under profiles/): these GEMMs are bound by the bytes a CU can stage per
+// second through its load path (35-50 GB/s/CU sustained), not by MFMA issue, LDS or HBM, so the
+// levers are bytes per FLOP (tile size, full 128-byte lines) and how far ahead the DMA runs.
+//   wide <WM=2,WN=4,MI=8,NS=2>: 256x256, wave tile 128x64, 2 stages x 64 KiB; 16 KiB staged per 2.1
+//        MFLOP, DMA one step ahead.  Best for wide outputs (qkv, fc1).
+//   mid  <WM=4,WN=2,MI=4,NS=3>: 256x128, wave tile 64x64, 3 stages x 48 KiB; 24 KiB per 2.1 MFLOP
+//        but DMA two steps ahead and twice the tiles: for N = 768-class outputs (proj, fc2), where
+//        591 tiles of 256x256 make 2.3 rounds on 256 CUs.
+// K step j (stage s = j mod NS), registers holding the ks=0 fragments of step j on entry:
+//   half 1: MFMAs(j,ks0)  ||  LDS reads of (j,ks1)
+//   s_waitcnt lgkmcnt(0) vmcnt((NS-2)*PIECES) ; s_barrier  -> stage s is free, step j+1 has landed
+//   half 2: MFMAs(j,ks1)  ||  LDS reads of (j+1,ks0)  ||  LDS-DMA of step j+NS into stage s
+// The stream continues ACROSS tile boundaries (the DMA pointers switch to the next tile NS steps
+// early), so the next tile's first loads fly during the epilogue.  One raw s_barrier per K step;
+// every LDS read and DMA issue sits between MFMAs (sched_group_barrier pins the order).
 // =============================================================================================
 #ifndef RAJNI_GEMM_X_AUX
 #define RAJNI_GEMM_X_AUX 0   // cache-policy bits of the X (activation) LDS-DMA loads: 2 = nt
@@ -420,35 +428,52 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) 
 #define RAJNI_GEMM_W_AUX 0   // ... of the W (weight) loads
 #endif
 namespace wide {
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
-constexpr int STAGE_BYTES = 2 * X_BYTES;        // 64 KiB
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // 128 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
 
-// issue order of one half step: 8 groups of {4 MFMAs, 1 X (+1 W in the first 4 groups) fragment read,
-// 1 DMA piece}
-template <int G, bool READ, bool DMA>
+template <int WN_, int NS_> struct Cfg {
+  static constexpr int BN = WN_ * 64;
+  static constexpr int W_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = NS_ * STAGE_BYTES;
+  static constexpr int PW = BN / 64;             // W pieces (1 KiB) per wave per K step
+  static constexpr int PIECES = 4 + PW;          // + 4 X pieces
+};
+
+// issue order of one half step: MI groups of {4 MFMAs, fragment reads, DMA pieces}
+template <int G, int MI, bool DMA, int PIECES>
 __device__ __forceinline__ void sched_half() {
-  if constexpr (G < 8) {
+  if constexpr (G < MI) {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, G < 4 ? 2 : 1, 0);
-    if constexpr (DMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    sched_half<G + 1, READ, DMA>();
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((G + 1) * 4 / MI - G * 4 / MI), 0);
+    if constexpr (DMA) {
+      constexpr int nd = (G + 1) * PIECES / MI - G * PIECES / MI;
+      if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
+    }
+    sched_half<G + 1, MI, DMA, PIECES>();
   }
 }
+template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
+  static_assert(N == 0 || N == 6 || N == 8, "unsupported vmcnt");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+}
 
-template <int EPI, int ALOAD, bool SF32>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) {
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p) {
+  using C = Cfg<WN, NS>;
+  static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X and W pieces 4w..4w+3
+  // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
   const int r_in = lane >> 3, pch = lane & 7;
   XSource<ALOAD> xs[4];
-  const bf16_t* ws[4];
+  const bf16_t* ws[C::PW];
   auto point_at = [&](int tile) {   // DMA source pointers of a tile
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
 #pragma unroll
@@ -457,25 +482,29 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) 
       int m = tm * BM + row;
       if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
       xs[i].init(p, m, pch ^ key_x(row));
-      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * BN + row) * p.ldw + (pch ^ key_w(row)) * 8;  // W rows padded to 256
+    }
+#pragma unroll
+    for (int i = 0; i < C::PW; ++i) {
+      const int row = (wave * C::PW + i) * 8 + r_in;
+      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ key_w(row)) * 8;
     }
   };
+  auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
+    if (q < 4)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[q - 4] + k0), LDS_PTR(dx + X_BYTES + (wave * C::PW + q - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+  };
   auto stage = [&](int kt, int st) {
-    char* sx = smem + st * STAGE_BYTES;
-    char* sw = sx + X_BYTES;
-    const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
-    }
+    for (int q = 0; q < C::PIECES; ++q) dma_piece(q, kt * BK, smem + st * C::STAGE_BYTES);
   };
 
   // ---- fragment addresses: rows base + (lane&15) have key (lane&15)>>1 for every mi, the permuted
   //      W rows have one key for every ni, so each (operand, ks) needs ONE address + immediates
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
-  const int xr0 = wm * 128 + l15;
+  const int xr0 = wm * (MI * 16) + l15;
   const int wr0 = wn * 64 + 16 * (l15 >> 2) + (l15 & 3);
   int xo[2], wo[2];
 #pragma unroll
@@ -484,82 +513,79 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) 
     wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ key_w(wr0)) << 4);
   }
 
-  f32x4 acc[4][8];  // [ni][mi]
+  f32x4 acc[4][MI];  // [ni][mi]
 
   // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
-  // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage
-  // dst, one piece per MFMA group
-  auto half = [&](auto dma_c, bf16x8 (&xc)[8], bf16x8 (&wc)[4], bf16x8 (&xn)[8], bf16x8 (&wn_)[4],
+  // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage dst
+  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], bf16x8 (&wc)[4], bf16x8 (&xn)[MI], bf16x8 (&wn_)[4],
                   int rst, int rks, int dkt, int dst) {
     constexpr bool DMA = decltype(dma_c)::value;
-    const char* sb = smem + rst * STAGE_BYTES;
-    char* dx = smem + dst * STAGE_BYTES + wave * 4096;
+    const char* sb = smem + rst * C::STAGE_BYTES;
+    char* dx = smem + dst * C::STAGE_BYTES;
     const int k0 = dkt * BK;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
-      if (mi < 4) wn_[mi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + mi * 512);
-      if constexpr (DMA) {  // piece mi of this wave: X pieces 0..3 then W pieces 0..3
-        if (mi < 4)
-          __builtin_amdgcn_global_load_lds(GLB_PTR(xs[mi].at(p, k0)), LDS_PTR(dx + mi * 1024), 16, 0, RAJNI_GEMM_X_AUX);
-        else
-          __builtin_amdgcn_global_load_lds(GLB_PTR(ws[mi - 4] + k0), LDS_PTR(dx + X_BYTES + (mi - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+#pragma unroll
+      for (int wi = mi * 4 / MI; wi < (mi + 1) * 4 / MI; ++wi)
+        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + wi * 512);
+      if constexpr (DMA) {
+#pragma unroll
+        for (int q = mi * C::PIECES / MI; q < (mi + 1) * C::PIECES / MI; ++q) dma_piece(q, k0, dx);
       }
     }
-    sched_half<0, true, DMA>();
+    sched_half<0, MI, DMA, C::PIECES>();
   };
   using T = std::true_type; using F = std::false_type;
 
-  // ---- persistent: this workgroup walks tiles v = blockIdx.x, +gridDim.x, ... as ONE stream of K
-  //      steps.  The DMA runs two steps ahead of the MFMAs ACROSS tile boundaries, so the next tile's
-  //      first loads are in flight while this tile's epilogue runs.
-  const int nk = p.K / BK;        // >= 3 (host checked)
+  const int nk = p.K / BK;        // >= NS + 1 (host checked)
   int v = blockIdx.x;
   int tile = xcd_tile_of(v, p.total_tiles);
-  bf16x8 xa[8], wa[4], xb[8], wb[4];
+  bf16x8 xa[MI], wa[4], xb[MI], wb[4];
   point_at(tile);
-  stage(0, 0);
-  stage(1, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NS; ++j) stage(j, j);
+  wait_step<(NS - 1) * C::PIECES == 12 ? 0 : (NS - 1) * C::PIECES>();   // step 0 landed (NS=3: drain all)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + i * 512);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
-  int par = 0;  // LDS stage of the current K step
+  for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
+  int st = 0;  // LDS stage of the current K step
 
   while (true) {
 #ifdef RAJNI_GEMM_STAMPS
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * C::BN;
     const int vn = v + gridDim.x;
     const bool more = vn < p.total_tiles;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
-      // the DMA of step kt loads K-tile kt+2; from kt = nk-2 on that is the NEXT tile's K-tile 0/1
-      // (when there is no next tile the pointers stay put: harmless re-loads that nobody reads)
-      if (kt == nk - 2 && more) point_at(xcd_tile_of(vn, p.total_tiles));
-      const int dkt = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
-      half(F{}, xa, wa, xb, wb, par, 1, 0, 0);
-      // my reads of stage `par` are done and my DMA pieces of the next step have landed ...
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage par is free, stage par^1 readable
+      // the DMA of step kt loads K-tile kt+NS; from kt = nk-NS on that is the NEXT tile's K-tile
+      // 0.. (when there is no next tile the pointers stay put: harmless re-loads nobody reads)
+      if (kt == nk - NS && more) point_at(xcd_tile_of(vn, p.total_tiles));
+      const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
+      const int st1 = st + 1 == NS ? 0 : st + 1;
+      half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
+      // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
+      wait_step<(NS - 2) * C::PIECES>();
+      __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
-      half(T{}, xb, wb, xa, wa, par ^ 1, 0, dkt, par);
-      par ^= 1;
+      half(T{}, xb, wb, xa, wa, st1, 0, dkt, st);
+      st = st1;
     }
 #ifdef RAJNI_GEMM_STAMPS
-    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][7][3]));
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][MI - 1][3]));
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -573,8 +599,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_wide(const GemmParams p) 
       gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
     }
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int m = m0 + wm * 128 + mi * 16 + l15;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (MI * 16) + mi * 16 + l15;
       if (m >= p.M) continue;
       float vv[16];
 #pragma unroll
@@ -898,7 +924,7 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
 
 unsigned long long* g_stamps = nullptr;
 int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
-int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64 (tests)
+int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64, 5 mid 256x128x64 (tests)
 
 // rounds of workgroups a launch needs on 256 CUs at `per_cu` resident workgroups each, weighted by
 // the tile's relative duration: picks the tiling that finishes first
@@ -913,7 +939,8 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
-  if (mode == 4 && p.K < 192) mode = 2;   // the persistent 256x256 stream needs >= 3 K steps
+  if (mode == 4 && p.K < 192) mode = 2;   // the persistent streams need >= NS + 1 K steps
+  if (mode == 5 && p.K < 256) mode = 2;
   if (mode == 0) {
     // measured on ViT-B shapes (tools/gemm_bench.py, profiles/): the persistent 256x256 tiling wins
     // for wide outputs (qkv, fc1: 940 vs 750 TFLOP/s); for N = 768-class outputs (proj, fc2) its
@@ -921,17 +948,23 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
     else mode = 1;
   }
-  static bool attr[4] = {false, false, false, false};
+  static bool attr[5] = {false, false, false, false, false};
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
                  2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
   int rc;
   if (mode == 4) {
-    constexpr int lds = wide::LDS_BYTES;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_wide<EPI, ALOAD, SF32>, lds, attr[3])) != RAJNI_OK) return rc;
+    using C = wide::Cfg<4, 2>;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, 2>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((wide::gemm_bf16_tn_wide<EPI, ALOAD, SF32>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, 2>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+  } else if (mode == 5) {
+    using C = wide::Cfg<2, 3>;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+    p.total_tiles = t256;
+    const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
+    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else if (mode == 2) {
     constexpr int lds = pipe::Cfg<8>::LDS_BYTES;
     if ((rc = set_lds_attr(&pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 8>, lds, attr[0])) != RAJNI_OK) return rc;
