@@ -81,7 +81,8 @@ int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int
  * out [B,np,H*D].  D must be 64. */
 int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                     int H, int D, float scale, int dtype, rajni_stream_t stream);
-/* test hook: 0 = choose by np (default), 1 = chunked online-softmax kernel, 2 = full-row kernel (np <= 256) */
+/* test hook: 0 = choose by np (default: persistent full-row kernel for np <= 256), 1 = chunked online-softmax
+ * kernel, 2 = one-shot full-row kernel (np <= 256) */
 void rajni_debug_force_attention(int mode);
 
 /* ---- LayerNorm over the last axis (blk.norm1 / norm2 / m.norm)            model.py:51,59,65 ----

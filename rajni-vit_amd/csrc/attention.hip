@@ -199,53 +199,13 @@ __global__ void __launch_bounds__(AT_THREADS) attn_bf16_d64(const AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int ATF_THREADS = 512;
 
+// exact-softmax attention of ONE 32-query tile against all NSUB*32 staged keys (shared by the
+// one-shot and the persistent kernels).  sk/sv: swizzled K / V images in LDS; qf: Q fragments.
 template <int NSUB>
-__global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWS = NSUB * 32;
-  char* sk = smem;
-  char* sv = smem + ROWS * 128;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv, const bf16x8 (&qf)[4],
+                                                  const AttnArgs& a, int b, int head, int qbase, int lane) {
   const int l31 = lane & 31, h = lane >> 5, g = lane >> 4, l15 = lane & 15;
-  const int head = blockIdx.x, b = blockIdx.y;
-  const int np = a.np, C = a.H * 64, C3 = 3 * C;
-  const bf16_t* img = a.qkv + (long)b * a.n_src * C3;
-  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
-  const int qbase = wave * 32;
-  const bool active = qbase < np;
-
-  // ---- Q fragments from HBM while K/V are staged
-  bf16x8 qf[4];
-  {
-    int q = qbase + l31;
-    if (q > np - 1) q = np - 1;
-    const int srow = idx ? idx[q] : q;
-    const bf16_t* qp = img + (long)srow * C3 + head * 64 + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-  }
-  // ---- stage all K and V rows (gathered through keep_idx), zero-fill up to ROWS
-  {
-    const int st_c = tid & 7, st_r = tid >> 3;  // 64 rows per pass
-#pragma unroll
-    for (int i = 0; i < (ROWS + 63) / 64; ++i) {
-      const int t = st_r + 64 * i;
-      if (t < ROWS) {
-        uint4 kr = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
-        if (t < np) {
-          const int srow = idx ? idx[t] : t;
-          const bf16_t* rp = img + (long)srow * C3 + head * 64 + st_c * 8;
-          kr = *reinterpret_cast<const uint4*>(rp + C);
-          vr = *reinterpret_cast<const uint4*>(rp + 2 * C);
-        }
-        *reinterpret_cast<uint4*>(sk + k_off(t, st_c)) = kr;
-        *reinterpret_cast<uint4*>(sv + v_off(t, st_c)) = vr;
-      }
-    }
-  }
-  __syncthreads();
-  if (!active) return;
-
+  const int np = a.np, C = a.H * 64;
   // ---- S^T = K Q^T for every 32-key block
   f32x16 s[NSUB];
 #pragma unroll
@@ -322,6 +282,151 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnA
       *reinterpret_cast<uint2*>(op + 8 * t) = w0;
       *reinterpret_cast<uint2*>(op + 32 + 8 * t) = w1;
     }
+  }
+}
+
+template <int NSUB>
+__global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NSUB * 32;
+  char* sk = smem;
+  char* sv = smem + ROWS * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5, g = lane >> 4, l15 = lane & 15;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int np = a.np, C = a.H * 64, C3 = 3 * C;
+  const bf16_t* img = a.qkv + (long)b * a.n_src * C3;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+  const int qbase = wave * 32;
+  const bool active = qbase < np;
+
+  // ---- Q fragments from HBM while K/V are staged
+  bf16x8 qf[4];
+  {
+    int q = qbase + l31;
+    if (q > np - 1) q = np - 1;
+    const int srow = idx ? idx[q] : q;
+    const bf16_t* qp = img + (long)srow * C3 + head * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  // ---- stage all K and V rows (gathered through keep_idx), zero-fill up to ROWS
+  {
+    const int st_c = tid & 7, st_r = tid >> 3;  // 64 rows per pass
+#pragma unroll
+    for (int i = 0; i < (ROWS + 63) / 64; ++i) {
+      const int t = st_r + 64 * i;
+      if (t < ROWS) {
+        uint4 kr = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
+        if (t < np) {
+          const int srow = idx ? idx[t] : t;
+          const bf16_t* rp = img + (long)srow * C3 + head * 64 + st_c * 8;
+          kr = *reinterpret_cast<const uint4*>(rp + C);
+          vr = *reinterpret_cast<const uint4*>(rp + 2 * C);
+        }
+        *reinterpret_cast<uint4*>(sk + k_off(t, st_c)) = kr;
+        *reinterpret_cast<uint4*>(sv + v_off(t, st_c)) = vr;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  attn_tile_compute<NSUB>(sk, sv, qf, a, b, head, qbase, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the kernel above: workgroups walk (image, head) items; K/V of item i+1 are
+// LDS-DMA'd (row gather through keep_idx on the per-lane SOURCE address, swizzle folded into it)
+// into the other LDS buffer while item i is computed; Q fragments and the keep_idx entries are
+// prefetched one / two items ahead.  One barrier per item.  Keys past np re-load row np-1 (finite)
+// and are masked in the softmax, so no zero fill is needed.
+// ---------------------------------------------------------------------------------------------
+template <int NSUB>
+__global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const AttnArgs a, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NSUB * 32, BUF = ROWS * 256, NP8 = ROWS / 8;   // pieces (8 rows) per operand
+  constexpr int PER_WAVE = (NP8 + 7) / 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int np = a.np, C = a.H * 64, C3 = 3 * C;
+  const int qbase = wave * 32;
+  const bool active = qbase < np;
+  const int r_in = lane >> 3, pos = lane & 7;
+
+  // token (packed index) of the rows this lane stages, and of its query row
+  int trow[PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int t = (wave + 8 * i) * 8 + r_in;
+    trow[i] = t < np ? t : np - 1;
+  }
+  const int tq = qbase + l31 < np ? qbase + l31 : np - 1;
+
+  auto load_rows = [&](int item, int (&srow)[PER_WAVE], int& sq) {   // keep_idx entries of an item
+    const int b = item / a.H;
+    const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) srow[i] = idx ? idx[trow[i]] : trow[i];
+    sq = idx ? idx[tq] : tq;
+  };
+  auto dma_item = [&](int item, const int (&srow)[PER_WAVE], int buf) {
+    const int b = item / a.H, head = item - b * a.H;
+    const bf16_t* img = a.qkv + (long)b * a.n_src * C3 + head * 64;
+    char* sk = smem + buf * BUF;
+    char* sv = sk + ROWS * 128;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave + 8 * i;            // piece index, wave uniform
+      if (q < NP8) {
+        const int row = q * 8 + r_in;
+        const bf16_t* rp = img + (long)srow[i] * C3;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(rp + C + ((pos ^ ((row >> 1) & 7)) << 3)), LDS_PTR(sk + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(rp + 2 * C + ((pos ^ (((row >> 1) & 1) << 2)) << 3)), LDS_PTR(sv + q * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto load_q = [&](int item, int sq, bf16x8 (&qf)[4]) {
+    const int b = item / a.H, head = item - b * a.H;
+    const bf16_t* qp = a.qkv + ((long)b * a.n_src + sq) * C3 + head * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  int srow_n[PER_WAVE], sq_n;
+  bf16x8 qf[4], qn[4];
+  load_rows(item, srow_n, sq_n);
+  dma_item(item, srow_n, 0);
+  load_q(item, sq_n, qf);
+  int nxt = item + gridDim.x;
+  if (nxt < n_items) load_rows(nxt, srow_n, sq_n);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int buf = 0;
+  while (true) {
+    const bool has_next = nxt < n_items;
+    if (has_next) {   // item i+1: K/V DMA into the other buffer, Q into registers; item i+2: indices
+      dma_item(nxt, srow_n, buf ^ 1);
+      load_q(nxt, sq_n, qn);
+      const int nn = nxt + gridDim.x;
+      if (nn < n_items) load_rows(nn, srow_n, sq_n);
+    }
+    if (active) {
+      const int b = item / a.H, head = item - b * a.H;
+      attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane);
+    }
+    if (!has_next) break;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my LDS reads are done
+    __builtin_amdgcn_s_barrier();                                  // ... everyone's
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    item = nxt;
+    nxt += gridDim.x;
+    buf ^= 1;
   }
 }
 
@@ -408,20 +513,29 @@ __global__ void __launch_bounds__(256) attn_f32_d64(const AttnArgsF32 a) {
   }
 }
 
+int g_force_attn = 0;  // 0 auto (persistent), 1 chunked online-softmax kernel, 2 one-shot full-row kernel (tests)
+
 template <int NSUB>
 int launch_full(const AttnArgs& a, int B, hipStream_t s) {
-  constexpr int lds = NSUB * 32 * 128 * 2;
+  if (g_force_attn == 2) {
+    constexpr int lds = NSUB * 32 * 128 * 2;
+    hipLaunchKernelGGL(attn_bf16_d64_full<NSUB>, dim3(a.H, B), dim3(ATF_THREADS), lds, s, a);
+    return RAJNI_OK;
+  }
+  constexpr int lds = NSUB * 32 * 256 * 2;   // two K+V buffers
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_d64_full<NSUB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { rajni_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e)); return RAJNI_ERR_LAUNCH; }
     attr = true;
   }
-  hipLaunchKernelGGL(attn_bf16_d64_full<NSUB>, dim3(a.H, B), dim3(ATF_THREADS), lds, s, a);
+  const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;   // 512-thread workgroups resident per CU
+  const int items = a.H * B;
+  const int grid = items < 256 * per_cu ? items : 256 * per_cu;
+  hipLaunchKernelGGL(attn_bf16_d64_stream<NSUB>, dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
   return RAJNI_OK;
 }
-int g_force_attn = 0;  // 0 auto, 1 chunked online-softmax kernel, 2 full-row kernel (tests)
 
 }  // namespace
 

@@ -218,7 +218,7 @@ def test_score_select_fused(B, N, H):
 # attention
 # ---------------------------------------------------------------------------------------------
 
-@pytest.fixture(params=[1, 2], ids=["online_chunked", "full_row"])
+@pytest.fixture(params=[0, 1, 2], ids=["persistent", "online_chunked", "full_row"])
 def attn_mode(request):
     """Both attention kernels (np <= 256 may use either) must agree with the oracle."""
     nat.lib().rajni_debug_force_attention(request.param)
