@@ -456,8 +456,10 @@ __device__ __forceinline__ void sched_half() {
   }
 }
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
-  static_assert(N == 0 || N == 6 || N == 8, "unsupported vmcnt");
+  static_assert(N == 0 || N == 1 || N == 6 || N == 7 || N == 8, "unsupported vmcnt");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else if (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 }
