@@ -158,6 +158,144 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb,
   }
 }
 
+// ---- fp32 residual stream epilogues (RESID / PATCH with SF32) use the NATURAL column order --------
+// With the permuted order a lane owns 16 consecutive columns = 64 bytes of fp32, so each of its four
+// 16-byte accesses lands in a different 64-byte sector from its three row neighbours: one wave
+// instruction touches 64 sectors.  Measured (tools/proj_probe.py): the fp32-stream proj GEMM took 151 us
+// against 72 us with a bias-only bf16 epilogue.  In the natural order (W fragment row r of n-tile ni =
+// column 16*ni + r) a lane owns columns 16*ni + 4*g + {0..3}: the four lanes of a row cover one whole
+// 64-byte sector per access - 16 sectors per wave instruction, 4x fewer memory transactions.
+constexpr bool nat_order(int epi, bool sf32) { return sf32 && (epi == EPI_RESID || epi == EPI_PATCH); }
+
+// column of accumulator element j = ni*4 + rg of a lane in lane group g; n0w = first column of the wave
+template <bool NAT>
+__device__ __forceinline__ int out_col(int n0w, int g, int j) {
+  return NAT ? n0w + 16 * (j >> 2) + 4 * g + (j & 3) : n0w + 16 * g + j;
+}
+
+// natural-order epilogue of one output row (fp32 stream): v = accumulators + bias on entry
+template <int EPI>
+__device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int n0w, int g, float* v, const float* gam) {
+  long orow = m, rrow = m;
+  int pp = 0;
+  if (EPI == EPI_RESID && p.ridx != nullptr) {
+    const int b = m / p.r_np;
+    rrow = (long)b * p.r_nsrc + p.ridx[m];
+  }
+  if (EPI == EPI_PATCH) {
+    const int b = m / p.npatch;
+    pp = m - b * p.npatch;
+    orow = (long)b * (p.npatch + 1) + 1 + pp;
+  }
+  const float* R = reinterpret_cast<const float*>(p.R);
+  const bf16_t* P = reinterpret_cast<const bf16_t*>(p.pos);
+  float* Y = reinterpret_cast<float*>(p.Y);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int c = n0w + 16 * ni + 4 * g;
+    float* vv = v + 4 * ni;
+    if (c + 4 <= p.N) {
+      if (EPI == EPI_RESID) {
+        const float4 r = *reinterpret_cast<const float4*>(R + rrow * p.ldr + c);
+        vv[0] = fmaf(gam[4 * ni + 0], vv[0], r.x); vv[1] = fmaf(gam[4 * ni + 1], vv[1], r.y);
+        vv[2] = fmaf(gam[4 * ni + 2], vv[2], r.z); vv[3] = fmaf(gam[4 * ni + 3], vv[3], r.w);
+      } else {
+        const uint2 q = *reinterpret_cast<const uint2*>(P + (long)(pp + p.pos_off) * p.ldc + c);
+        vv[0] += bf_lo(q.x); vv[1] += bf_hi(q.x); vv[2] += bf_lo(q.y); vv[3] += bf_hi(q.y);
+      }
+      *reinterpret_cast<float4*>(Y + orow * p.ldc + c) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < p.N) {
+          float o = vv[e];
+          if (EPI == EPI_RESID) o = fmaf(gam[4 * ni + e], o, R[rrow * p.ldr + c + e]);
+          else o += bf2f(P[(long)(pp + p.pos_off) * p.ldc + c + e]);
+          Y[orow * p.ldc + c + e] = o;
+        }
+    }
+  }
+}
+
+// Residual rows of a tile, loaded EARLY (during the last K step) for the fp32-stream RESID epilogue:
+// that epilogue is a latency-bound HBM stream with only 8 waves per CU, so what sets its rate is how
+// many loads are in flight and how much of their latency hides under MFMAs.  Measured on proj
+// (tools/proj_probe.py): 155 us -> 135 us with all loads of the tile issued before the first store,
+// -> (see profiles) with the loads issued one K step before the epilogue.
+template <int MI>
+struct ResidPrefetch {
+  float4 r[MI][4];
+  bool valid;
+};
+template <int EPI, bool SF32, int MI>
+__device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetch<MI>& pre, int m_base, int n0w,
+                                               int l15, int g) {
+  pre.valid = false;
+  if constexpr (nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4) {
+    if (n0w + 64 <= p.N && m_base + MI * 16 <= p.M) {   // interior tile: no guards needed
+      const float* R = reinterpret_cast<const float*>(p.R);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m_base + mi * 16 + l15;
+        long rrow = m;
+        if (p.ridx != nullptr) rrow = (long)(m / p.r_np) * p.r_nsrc + p.ridx[m];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          pre.r[mi][ni] = *reinterpret_cast<const float4*>(R + rrow * p.ldr + n0w + 16 * ni + 4 * g);
+      }
+      pre.valid = true;
+    }
+  }
+}
+
+// shared tail of every bf16 tiling: bias/gamma for this lane's columns, then one row per m-tile
+template <int EPI, bool SF32, int MI>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[4][MI], int m_base, int n0w,
+                                              int l15, int g, const ResidPrefetch<MI>& pre) {
+  constexpr bool NAT = nat_order(EPI, SF32);
+  float bias[16], gam[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = out_col<NAT>(n0w, g, j);
+    bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
+  }
+  if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
+    if (pre.valid) {   // interior tile whose residual rows were prefetched during the last K step
+      float* Y = reinterpret_cast<float*>(p.Y);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float4 o;
+          o.x = fmaf(gam[4 * ni + 0], acc[ni][mi][0] + bias[4 * ni + 0], pre.r[mi][ni].x);
+          o.y = fmaf(gam[4 * ni + 1], acc[ni][mi][1] + bias[4 * ni + 1], pre.r[mi][ni].y);
+          o.z = fmaf(gam[4 * ni + 2], acc[ni][mi][2] + bias[4 * ni + 2], pre.r[mi][ni].z);
+          o.w = fmaf(gam[4 * ni + 3], acc[ni][mi][3] + bias[4 * ni + 3], pre.r[mi][ni].w);
+          *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g) = o;
+        }
+      return;
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m_base + mi * 16 + l15;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+    if (NAT) epilogue_row_nat<EPI>(p, m, n0w, g, v, gam);
+    else epilogue_row<EPI, SF32>(p, m, n0w + 16 * g, v, gam);
+  }
+}
+// W tile row read by fragment row r (= lane&15) of n-tile ni, relative to the wave's first W row
+template <bool NAT>
+__device__ __forceinline__ int w_frag_row(int l15, int ni) {
+  return NAT ? ni * 16 + l15 : 16 * (l15 >> 2) + ni * 4 + (l15 & 3);
+}
+
 // XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous range of tiles
 __device__ __forceinline__ int xcd_tile_of(int v, int total) {
   const int q = total >> 3, r = total & 7, xcd = v & 7, loc = v >> 3;
@@ -442,6 +580,16 @@ template <int WN_, int NS_> struct Cfg {
   static constexpr int PIECES = 4 + PW;          // + 4 X pieces
 };
 
+// first DMA piece issued after MFMA group g of a half step.  RAJNI_GEMM_DMA_FRONT pieces per group
+// until they run out (front-loaded: the pieces must land by the NEXT mid-step barrier, so the earlier
+// in the half step they are issued the more of their latency is hidden); 0 = spread evenly
+#ifndef RAJNI_GEMM_DMA_FRONT
+#define RAJNI_GEMM_DMA_FRONT 0
+#endif
+__host__ __device__ constexpr int dma_first(int g, int pieces, int groups) {
+  return RAJNI_GEMM_DMA_FRONT > 0 ? (g * RAJNI_GEMM_DMA_FRONT < pieces ? g * RAJNI_GEMM_DMA_FRONT : pieces)
+                                  : g * pieces / groups;
+}
 // issue order of one half step: MI groups of {4 MFMAs, fragment reads, DMA pieces}
 template <int G, int MI, bool DMA, int PIECES>
 __device__ __forceinline__ void sched_half() {
@@ -449,7 +597,7 @@ __device__ __forceinline__ void sched_half() {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((G + 1) * 4 / MI - G * 4 / MI), 0);
     if constexpr (DMA) {
-      constexpr int nd = (G + 1) * PIECES / MI - G * PIECES / MI;
+      constexpr int nd = dma_first(G + 1, PIECES, MI) - dma_first(G, PIECES, MI);
       if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
     }
     sched_half<G + 1, MI, DMA, PIECES>();
@@ -467,6 +615,7 @@ template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) +
 template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p) {
   using C = Cfg<WN, NS>;
+  constexpr bool NAT = nat_order(EPI, SF32);   // natural W-row / column order for fp32-stream epilogues
   static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -488,7 +637,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #pragma unroll
     for (int i = 0; i < C::PW; ++i) {
       const int row = (wave * C::PW + i) * 8 + r_in;
-      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ key_w(row)) * 8;
+      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ (NAT ? key_x(row) : key_w(row))) * 8;
     }
   };
   auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
@@ -507,12 +656,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
   const int xr0 = wm * (MI * 16) + l15;
-  const int wr0 = wn * 64 + 16 * (l15 >> 2) + (l15 & 3);
+  const int wr0 = wn * 64 + w_frag_row<NAT>(l15, 0);
+  constexpr int W_NI_STRIDE = NAT ? 16 * 128 : 4 * 128;   // bytes between the W rows of consecutive n-tiles
   int xo[2], wo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     xo[ks] = xr0 * 128 + (((ks * 4 + g) ^ key_x(xr0)) << 4);
-    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ key_w(wr0)) << 4);
+    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ (NAT ? key_x(wr0) : key_w(wr0))) << 4);
   }
 
   f32x4 acc[4][MI];  // [ni][mi]
@@ -533,10 +683,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
 #pragma unroll
       for (int wi = mi * 4 / MI; wi < (mi + 1) * 4 / MI; ++wi)
-        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + wi * 512);
+        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + wi * W_NI_STRIDE);
       if constexpr (DMA) {
 #pragma unroll
-        for (int q = mi * C::PIECES / MI; q < (mi + 1) * C::PIECES / MI; ++q) dma_piece(q, k0, dx);
+        for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
       }
     }
     sched_half<0, MI, DMA, C::PIECES>();
@@ -554,7 +704,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + i * 512);
+  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + i * W_NI_STRIDE);
 #pragma unroll
   for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
   int st = 0;  // LDS stage of the current K step
@@ -567,6 +717,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     const int m0 = tm * BM, n0 = tn * C::BN;
     const int vn = v + gridDim.x;
     const bool more = vn < p.total_tiles;
+    ResidPrefetch<MI> pre;
+    pre.valid = false;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -578,6 +730,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       if (kt == nk - NS && more) point_at(xcd_tile_of(vn, p.total_tiles));
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
+      if (kt == nk - 1) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
       half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
       wait_step<(NS - 2) * C::PIECES>();
@@ -591,26 +744,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- epilogue: lane owns row m and columns nb .. nb+15 (next tile's loads are in flight)
-    const int nb = n0 + wn * 64 + 16 * g;
-    float bias[16], gam[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int n = nb + j;
-      bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-      gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * (MI * 16) + mi * 16 + l15;
-      if (m >= p.M) continue;
-      float vv[16];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) vv[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-      epilogue_row<EPI, SF32>(p, m, nb, vv, gam);
-    }
+    // ---- epilogue (the next tile's first loads are in flight)
+    epilogue_tile<EPI, SF32, MI>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -642,6 +777,7 @@ __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((
 
 template <int EPI, int ALOAD, bool SF32>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams p) {
+  constexpr bool NAT = nat_order(EPI, SF32);   // natural W-row / column order for fp32-stream epilogues
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -659,7 +795,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     xs[i].init(p, m, pch ^ key_x(row));
-    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ key_w(row)) * 8;
+    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ (NAT ? key_x(row) : key_w(row))) * 8;
   }
   auto stage = [&](int kt, int buf) {
     char* sx = smem + buf * STAGE_BYTES;
@@ -680,8 +816,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
   for (int i = 0; i < 4; ++i) {
     const int xr = wm * 64 + i * 16 + l15;
     xoff[i] = xr * 128; xkey[i] = key_x(xr);
-    const int wr = wn * 64 + 16 * (l15 >> 2) + i * 4 + (l15 & 3);
-    woff[i] = wr * 128; wkey[i] = key_w(wr);
+    const int wr = wn * 64 + w_frag_row<NAT>(l15, i);
+    woff[i] = wr * 128; wkey[i] = NAT ? key_x(wr) : key_w(wr);
   }
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -691,11 +827,14 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
+  ResidPrefetch<4> pre;
+  pre.valid = false;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed for every wave; everyone is done reading the other buffer
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    else prefetch_resid<EPI, SF32, 4>(p, pre, m0 + wm * 64, n0 + wn * 64, l15, g);   // lands under the last MFMAs
     const char* sx = smem + (kt & 1) * STAGE_BYTES;
     const char* sw = sx + TILE_BYTES;
 #pragma unroll
@@ -715,25 +854,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     }
   }
 
-  const int nb = n0 + wn * 64 + 16 * g;
-  float bias[16], gam[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int n = nb + j;
-    bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-    gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + l15;
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-    epilogue_row<EPI, SF32>(p, m, nb, v, gam);
-  }
+  epilogue_tile<EPI, SF32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g, pre);
 }
 }  // namespace small
 
@@ -944,10 +1065,13 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4 && p.K < 192) mode = 2;   // the persistent streams need >= NS + 1 K steps
   if (mode == 5 && p.K < 256) mode = 2;
   if (mode == 0) {
-    // measured on ViT-B shapes (tools/gemm_bench.py, profiles/): the persistent 256x256 tiling wins
-    // for wide outputs (qkv, fc1: 940 vs 750 TFLOP/s); for N = 768-class outputs (proj, fc2) its
-    // 256-CU rounds quantise badly (591 tiles = 2.3 rounds) and the 128x128 tiling is faster.
+    // measured on ViT-B shapes (tools/gemm_bench.py, tools/proj_probe.py, profiles/):
+    //   wide outputs (qkv, fc1): persistent 256x256 (950 / 870 TFLOP/s vs 750 / 700 for 128x128);
+    //   N = 768-class outputs (proj, fc2): 591 tiles of 256x256 make 2.3 rounds on 256 CUs, the
+    //   persistent 256x128 3-stage tiling is best (proj 125 us, fc2 284 us vs 127 / 310 for 128x128);
+    //   small problems (head, tiny batches): 128x128.
     if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
+    else if (p.M >= 1024 && p.K >= 256) mode = 5;
     else mode = 1;
   }
   static bool attr[5] = {false, false, false, false, false};
