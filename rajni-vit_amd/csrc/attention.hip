@@ -28,6 +28,7 @@ struct AttnArgs {
   bf16_t* out;      // [B,np,H*64]
   int n_src, np, H;
   float c;          // scale * log2(e)
+  unsigned long long* stamps;   // diagnostic builds (-DRAJNI_ATTN_STAMPS) only
 };
 
 __device__ __forceinline__ int k_off(int row, int chunk) {   // K tile: natural row reads
@@ -219,6 +220,10 @@ __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv
       s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
     }
   }
+#ifdef RAJNI_ATTN_STAMPS
+  asm volatile("" :: "v"(s[0][0]), "v"(s[NSUB - 1][15]));
+  const unsigned long long tsS = __builtin_amdgcn_s_memtime();
+#endif
   // mask the keys past np (only in the last block)
   {
     const int nvalid = np - (NSUB - 1) * 32;
@@ -268,6 +273,14 @@ __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb[s2], o1, 0, 0, 0);
     }
   }
+#ifdef RAJNI_ATTN_STAMPS
+  asm volatile("" :: "v"(o0[0]), "v"(o1[15]));
+  const unsigned long long tsP = __builtin_amdgcn_s_memtime();
+  if (a.stamps != nullptr && qbase == 0 && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)b * a.H + head) * 8;
+    o[1] = tsS; o[2] = tsP;
+  }
+#endif
   const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
   const int q = qbase + l31;
   if (q < np) {
@@ -341,6 +354,19 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnA
 // prefetched one / two items ahead.  One barrier per item.  Keys past np re-load row np-1 (finite)
 // and are masked in the softmax, so no zero fill is needed.
 // ---------------------------------------------------------------------------------------------
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at the wave-uniform LDS address `dst`) issued from inline
+// asm so that hipcc does NOT see it: with the builtin, hipcc (ROCm 7.2) drains the DMA (vmcnt(0)) before
+// every ds_read_b64_tr_b16 (possible alias) and before any use of an ordinary global load issued near it,
+// which serialised K/V prefetch with compute (tools/attn_stamps.py: 9.8k of 16.4k cycles per item).  Its
+// completion is counted by hand: s_waitcnt vmcnt(0) before the per-item barrier.  M0 is saved/restored
+// inside the statement (M0 is compiler-reserved); recipe: cdna_hip_programming.md section 5.7.
+__device__ __forceinline__ void dma16(const bf16_t* src, char* dst) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(dst));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
+
 template <int NSUB>
 __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -381,8 +407,8 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
       if (q < NP8) {
         const int row = q * 8 + r_in;
         const bf16_t* rp = img + (long)srow[i] * C3;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(rp + C + ((pos ^ ((row >> 1) & 7)) << 3)), LDS_PTR(sk + q * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(rp + 2 * C + ((pos ^ (((row >> 1) & 1) << 2)) << 3)), LDS_PTR(sv + q * 1024), 16, 0, 0);
+        dma16(rp + C + ((pos ^ ((row >> 1) & 7)) << 3), sk + q * 1024);
+        dma16(rp + 2 * C + ((pos ^ (((row >> 1) & 1) << 2)) << 3), sv + q * 1024);
       }
     }
   };
@@ -395,39 +421,49 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
 
   int item = blockIdx.x;
   if (item >= n_items) return;
-  int srow_n[PER_WAVE], sq_n;
+  // Software pipeline (i = item being computed):  K/V(i+1) by asm DMA, Q(i+1) and keep_idx(i+2) by
+  // ordinary loads, all issued right after the per-item barrier and left in flight during compute(i).
+  // hipcc must not wait for any of them inside compute: every ordinary-load result is "touched" by an
+  // empty asm right after the barrier, where the queue has just been drained by hand, so that is where
+  // hipcc places its (then free) waits.
+  int srow_a[PER_WAVE], sq_a;     // keep_idx entries of item i+1 (then i+2)
   bf16x8 qf[4], qn[4];
-  load_rows(item, srow_n, sq_n);
-  dma_item(item, srow_n, 0);
-  load_q(item, sq_n, qf);
+  load_rows(item, srow_a, sq_a);
+  dma_item(item, srow_a, 0);
+  load_q(item, sq_a, qn);
   int nxt = item + gridDim.x;
-  if (nxt < n_items) load_rows(nxt, srow_n, sq_n);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  load_rows(nxt < n_items ? nxt : n_items - 1, srow_a, sq_a);
   int buf = 0;
   while (true) {
-    const bool has_next = nxt < n_items;
-    if (has_next) {   // item i+1: K/V DMA into the other buffer, Q into registers; item i+2: indices
-      dma_item(nxt, srow_n, buf ^ 1);
-      load_q(nxt, sq_n, qn);
-      const int nn = nxt + gridDim.x;
-      if (nn < n_items) load_rows(nn, srow_n, sq_n);
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my LDS reads are done
+    __builtin_amdgcn_s_barrier();                                  // ... everyone's: buffer `buf` is complete
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { asm volatile("" : "+v"(qn[s])); qf[s] = qn[s]; }
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) asm volatile("" : "+v"(srow_a[i]));
+    asm volatile("" : "+v"(sq_a));
+    // prefetch for item i+1 / i+2, UNCONDITIONALLY (clamped to the last item: harmless re-loads that
+    // nobody reads) - a conditional load would need a register copy, and hipcc would wait for it here
+    const int last = n_items - 1;
+    const int nx = nxt < last ? nxt : last;
+    const int nn = nxt + (int)gridDim.x < last ? nxt + (int)gridDim.x : last;
+    int srow_use[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) srow_use[i] = srow_a[i];
+    load_q(nx, sq_a, qn);                      // Q of item i+1
+    load_rows(nn, srow_a, sq_a);               // keep_idx entries of item i+2
+    dma_item(nx, srow_use, buf ^ 1);           // K/V of item i+1 -> the other buffer
     if (active) {
       const int b = item / a.H, head = item - b * a.H;
       attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane);
     }
-    if (!has_next) break;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my LDS reads are done
-    __builtin_amdgcn_s_barrier();                                  // ... everyone's
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    if (nxt >= n_items) break;
     item = nxt;
     nxt += gridDim.x;
     buf ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (unused) DMA before LDS is released
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,6 +598,7 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   a.qkv = (const bf16_t*)qkv; a.idx = keep_idx; a.out = (bf16_t*)out;
   a.n_src = n_src; a.np = np; a.H = H;
   a.c = scale * 1.4426950408889634f;
+  a.stamps = rajni_g_stamps;
   const double flops = 4.0 * B * H * (double)np * np * D;
   const double bytes = 2.0 * B * (double)np * H * D * 4.0;
   ProfScope prof(KC_ATTENTION, s, flops, bytes);

@@ -28,6 +28,8 @@ const char* const kNames[RAJNI_NUM_KCLASS] = {
     "cls_pos_kernel", "other"};
 }  // namespace
 
+unsigned long long* rajni_g_stamps = nullptr;
+
 void rajni_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

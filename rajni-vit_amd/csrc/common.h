@@ -108,6 +108,9 @@ struct ProfScope {
     }                                        \
   } while (0)
 
+// diagnostic builds only (-DRAJNI_GEMM_STAMPS / -DRAJNI_ATTN_STAMPS): device buffer for s_memtime stamps
+extern unsigned long long* rajni_g_stamps;
+
 // internal launchers shared between the per-op ABI and the whole-forward plan
 int launch_linear(const rajni_linear_args& a, hipStream_t s);
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,

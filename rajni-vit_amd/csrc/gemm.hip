@@ -1045,7 +1045,6 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
   store1<SF32>(x, (long)b * img_stride + c, v);
 }
 
-unsigned long long* g_stamps = nullptr;
 int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
 int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64, 5 mid 256x128x64 (tests)
 
@@ -1058,7 +1057,7 @@ inline double launch_cost(int tiles, int per_cu, double tile_time) {
 
 template <int EPI, int ALOAD, bool SF32>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
-  p.stamps = g_stamps;
+  p.stamps = rajni_g_stamps;
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
@@ -1115,7 +1114,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
-extern "C" void rajni_debug_set_gemm_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }
 
 int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   RAJNI_REQUIRE(a.dtype == RAJNI_BF16 || a.dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_linear: bad dtype %d", a.dtype);

@@ -64,7 +64,8 @@ class RAJNIViTWrapper(nn.Module):
         self._last_stats = None
         self._weights = None       # packed device tensors (kept alive here)
         self._weights_key = None
-        self._plan = None          # (key, VitPlan, keep-alive objects)
+        self._plan = None          # most recent (key, VitPlan, keep-alive objects, stage buffers, counts)
+        self._plans = {}           # small cache by key: a ragged last batch must not evict the main plan
         self._forced: Dict[int, torch.Tensor] = {}
         self._trace_scores = False
         # residual stream precision between blocks: fp32 (default; see DESIGN.md "numerics") or the
@@ -95,16 +96,20 @@ class RAJNIViTWrapper(nn.Module):
             out[i] = d
         return out
 
+    def _drop_plans(self):
+        self._plan = None
+        self._plans = {}
+
     def set_residual_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("residual stream dtype must be torch.float32 or torch.bfloat16")
         self._resid_bf16 = dtype == torch.bfloat16
-        self._plan = None
+        self._drop_plans()
         return self
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
-        self._plan = None
+        self._drop_plans()
         return self
 
     def force_keep_idx(self, forced: Optional[Dict[int, torch.Tensor]]):
@@ -113,7 +118,7 @@ class RAJNIViTWrapper(nn.Module):
         self._forced = {}
         for k, v in (forced or {}).items():
             self._forced[int(k)] = v.to(torch.int32).contiguous()
-        self._plan = None
+        self._drop_plans()
         return self
 
     # ------------------------------------------------------------------------------------------
@@ -196,7 +201,7 @@ class RAJNIViTWrapper(nn.Module):
                 fc2_w=pw(blk.mlp.fc2.weight), fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
-        self._plan = None
+        self._drop_plans()
         return W
 
     def _build_plan(self, B: int, S: int, device, dtype):
@@ -204,6 +209,9 @@ class RAJNIViTWrapper(nn.Module):
         d = W["desc"]
         key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16)
         if self._plan is not None and self._plan[0] == key:
+            return self._plan
+        if key in self._plans:
+            self._plan = self._plans[key]
             return self._plan
         if S % d["patch"] != 0:
             raise ValueError(f"image size {S} is not a multiple of the patch size {d['patch']}")
@@ -265,6 +273,9 @@ class RAJNIViTWrapper(nn.Module):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes
         self._plan = (key, plan, (blocks, tc, ws), bufs, counts)
+        if len(self._plans) >= 4:     # workspaces are large: keep only a few batch shapes alive
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = self._plan
         return self._plan
 
     # ------------------------------------------------------------------------------------------
