@@ -111,13 +111,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
+    # rehearsal hooks for a 1-GPU box: RAJNI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # RAJNI_BENCH_BACKEND=gloo joins them over CPU tensors (RCCL refuses two ranks on one GPU)
+    if os.environ.get("RAJNI_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("RAJNI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rajni_amd
     from rajni_amd import timm_shaped as ts, _native as nat
@@ -148,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     nat.profile_enable(0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = nat.profile_collect()
