@@ -82,6 +82,16 @@ __device__ __forceinline__ void load16(const void* base, long off, float* f) {
   }
 }
 template <bool F32>
+__device__ __forceinline__ void load8s(const void* base, long off, float* f) {   // 8 stream elements
+  if (F32) load8<float>(reinterpret_cast<const float*>(base) + off, f);
+  else load8<bf16_t>(reinterpret_cast<const bf16_t*>(base) + off, f);
+}
+template <bool F32>
+__device__ __forceinline__ void store8s(void* base, long off, const float* v) {
+  if (F32) store8<float>(reinterpret_cast<float*>(base) + off, v);
+  else store8<bf16_t>(reinterpret_cast<bf16_t*>(base) + off, v);
+}
+template <bool F32>
 __device__ __forceinline__ float load1(const void* base, long off) {
   return F32 ? reinterpret_cast<const float*>(base)[off] : bf2f(reinterpret_cast<const bf16_t*>(base)[off]);
 }
@@ -105,9 +115,12 @@ __device__ __forceinline__ void store1(void* base, long off, float v) {
 
 // One output row m, columns nb..nb+15 (v = accumulators + bias on entry).
 // SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32.
+// v[0..7] are columns nbA..nbA+7 and v[8..15] columns nbB..nbB+7 of output row m (nbB = nbA + 8 for
+// the 16-consecutive mapping of the pipe tilings, nbA + 32 for the sector mapping below).
 template <int EPI, bool SF32>
-__device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb, float* v, const float* gam) {
+__device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nbA, int nbB, float* v, const float* gam) {
   long orow = m;
+  const bool full = nbB + 8 <= p.N;   // both halves inside N (nbA < nbB)
   if (EPI == EPI_GELU) {
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
@@ -120,41 +133,49 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb,
       const int b = m / p.r_np;
       rrow = (long)b * p.r_nsrc + p.ridx[m];
     }
-    const long roff = rrow * p.ldr + nb;
-    if (nb + 16 <= p.N) {
+    const long rbase = rrow * p.ldr;
+    if (full) {
       float rf[16];
-      load16<SF32>(p.R, roff, rf);
+      load8s<SF32>(p.R, rbase + nbA, rf);
+      load8s<SF32>(p.R, rbase + nbB, rf + 8);
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = fmaf(gam[j], v[j], rf[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (nb + j < p.N) v[j] = fmaf(gam[j], v[j], load1<SF32>(p.R, roff + j));
+      for (int j = 0; j < 16; ++j) {
+        const int n = (j < 8 ? nbA : nbB - 8) + j;
+        if (n < p.N) v[j] = fmaf(gam[j], v[j], load1<SF32>(p.R, rbase + n));
+      }
     }
   } else if (EPI == EPI_PATCH) {
     const int b = m / p.npatch, pp = m - b * p.npatch;
     orow = (long)b * (p.npatch + 1) + 1 + pp;
-    const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.pos) + (long)(pp + p.pos_off) * p.ldc + nb;
-    if (nb + 16 <= p.N) {
+    const bf16_t* pr = reinterpret_cast<const bf16_t*>(p.pos) + (long)(pp + p.pos_off) * p.ldc;
+    if (full) {
       float pf[16];
-      unpack8(*reinterpret_cast<const uint4*>(pr), pf);
-      unpack8(*reinterpret_cast<const uint4*>(pr + 8), pf + 8);
+      unpack8(*reinterpret_cast<const uint4*>(pr + nbA), pf);
+      unpack8(*reinterpret_cast<const uint4*>(pr + nbB), pf + 8);
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] += pf[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (nb + j < p.N) v[j] += bf2f(pr[j]);
+      for (int j = 0; j < 16; ++j) {
+        const int n = (j < 8 ? nbA : nbB - 8) + j;
+        if (n < p.N) v[j] += bf2f(pr[n]);
+      }
     }
   }
   constexpr bool OUT32 = SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH);
-  const long yoff = orow * p.ldc + nb;
-  if (nb + 16 <= p.N) {
-    store16<OUT32>(p.Y, yoff, v);
+  const long ybase = orow * p.ldc;
+  if (full) {
+    store8s<OUT32>(p.Y, ybase + nbA, v);
+    store8s<OUT32>(p.Y, ybase + nbB, v + 8);
   } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (nb + j < p.N) store1<OUT32>(p.Y, yoff + j, v[j]);
+    for (int j = 0; j < 16; ++j) {
+      const int n = (j < 8 ? nbA : nbB - 8) + j;
+      if (n < p.N) store1<OUT32>(p.Y, ybase + n, v[j]);
+    }
   }
 }
 
@@ -167,10 +188,38 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nb,
 // 64-byte sector per access - 16 sectors per wave instruction, 4x fewer memory transactions.
 constexpr bool nat_order(int epi, bool sf32) { return sf32 && (epi == EPI_RESID || epi == EPI_PATCH); }
 
-// column of accumulator element j = ni*4 + rg of a lane in lane group g; n0w = first column of the wave
-template <bool NAT>
+// Which W tile row feeds fragment row r of n-tile ni decides which output columns a lane owns
+// (accumulator element j = ni*4 + rg of a lane in lane group g; n0w = first column of the wave):
+//   MAP_NAT  col = 16*ni + 4*g + rg          fp32 stream: 4 lanes of a row = one 64-byte sector (above)
+//   MAP_SEC  col = 32*(ni>>1) + 8*g + 4*(ni&1) + rg   bf16 outputs: a lane owns 2 x 8 consecutive columns
+//            and the 4 lanes of a row write one whole 64-byte sector per 16-byte store instruction.
+//            (With 16 consecutive columns per lane every store instruction wrote 4 quarter sectors
+//            per row: the wide tiling's epilogue took 9.5k cycles per 256x256 tile, store-issue bound.)
+//   MAP_P16  col = 16*g + 4*ni + rg          16 consecutive columns per lane (pipe tilings only)
+enum { MAP_P16 = 0, MAP_NAT = 1, MAP_SEC = 2 };
+constexpr int col_map(int epi, bool sf32) { return nat_order(epi, sf32) ? MAP_NAT : MAP_SEC; }
+
+template <int MAP>
 __device__ __forceinline__ int out_col(int n0w, int g, int j) {
-  return NAT ? n0w + 16 * (j >> 2) + 4 * g + (j & 3) : n0w + 16 * g + j;
+  const int ni = j >> 2, rg = j & 3;
+  return MAP == MAP_NAT ? n0w + 16 * ni + 4 * g + rg
+       : MAP == MAP_SEC ? n0w + 32 * (ni >> 1) + 8 * g + 4 * (ni & 1) + rg
+                        : n0w + 16 * g + j;
+}
+// W tile row (relative to the wave's first W row) read by fragment row l15 of n-tile ni
+template <int MAP>
+__device__ __forceinline__ int w_frag_row(int l15, int ni) {
+  return MAP == MAP_NAT ? ni * 16 + l15
+       : MAP == MAP_SEC ? 32 * (ni >> 1) + 8 * (l15 >> 2) + 4 * (ni & 1) + (l15 & 3)
+                        : 16 * (l15 >> 2) + ni * 4 + (l15 & 3);
+}
+// swizzle key of a W tile row for 128-byte-row tilings: the 16 rows one ds_read_b128 lane group
+// touches must land in 16 distinct 16-byte slots of the 256-byte bank row
+template <int MAP>
+__device__ __forceinline__ int w_key(int row) {
+  return MAP == MAP_NAT ? (row >> 1) & 7
+       : MAP == MAP_SEC ? ((row >> 3) & 3) * 2 + ((row >> 1) & 1)
+                        : ((row >> 4) & 3) * 2 + ((row >> 1) & 1);
 }
 
 // natural-order epilogue of one output row (fp32 stream): v = accumulators + bias on entry
@@ -252,11 +301,12 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 template <int EPI, bool SF32, int MI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[4][MI], int m_base, int n0w,
                                               int l15, int g, const ResidPrefetch<MI>& pre) {
-  constexpr bool NAT = nat_order(EPI, SF32);
+  constexpr int MAP = col_map(EPI, SF32);
+  constexpr bool NAT = MAP == MAP_NAT;
   float bias[16], gam[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int n = out_col<NAT>(n0w, g, j);
+    const int n = out_col<MAP>(n0w, g, j);
     bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
     gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
   }
@@ -287,15 +337,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
     if (NAT) epilogue_row_nat<EPI>(p, m, n0w, g, v, gam);
-    else epilogue_row<EPI, SF32>(p, m, n0w + 16 * g, v, gam);
+    else epilogue_row<EPI, SF32>(p, m, n0w + 8 * g, n0w + 32 + 8 * g, v, gam);
   }
 }
-// W tile row read by fragment row r (= lane&15) of n-tile ni, relative to the wave's first W row
-template <bool NAT>
-__device__ __forceinline__ int w_frag_row(int l15, int ni) {
-  return NAT ? ni * 16 + l15 : 16 * (l15 >> 2) + ni * 4 + (l15 & 3);
-}
-
 // XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous range of tiles
 __device__ __forceinline__ int xcd_tile_of(int v, int total) {
   const int q = total >> 3, r = total & 7, xcd = v & 7, loc = v >> 3;
@@ -535,7 +579,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) 
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-    epilogue_row<EPI, SF32>(p, m, nb, v, gam);
+    epilogue_row<EPI, SF32>(p, m, nb, nb + 8, v, gam);
   }
 }
 }  // namespace pipe
@@ -615,7 +659,7 @@ template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) +
 template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p) {
   using C = Cfg<WN, NS>;
-  constexpr bool NAT = nat_order(EPI, SF32);   // natural W-row / column order for fp32-stream epilogues
+  constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
   static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -637,7 +681,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #pragma unroll
     for (int i = 0; i < C::PW; ++i) {
       const int row = (wave * C::PW + i) * 8 + r_in;
-      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ (NAT ? key_x(row) : key_w(row))) * 8;
+      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8;
     }
   };
   auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
@@ -656,13 +700,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
   const int xr0 = wm * (MI * 16) + l15;
-  const int wr0 = wn * 64 + w_frag_row<NAT>(l15, 0);
-  constexpr int W_NI_STRIDE = NAT ? 16 * 128 : 4 * 128;   // bytes between the W rows of consecutive n-tiles
+  const int wr0 = wn * 64 + w_frag_row<MAP>(l15, 0);
+  // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same)
+  auto w_ni_off = [](int ni) { return (w_frag_row<MAP>(0, ni) - w_frag_row<MAP>(0, 0)) * 128; };
   int xo[2], wo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     xo[ks] = xr0 * 128 + (((ks * 4 + g) ^ key_x(xr0)) << 4);
-    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ (NAT ? key_x(wr0) : key_w(wr0))) << 4);
+    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ w_key<MAP>(wr0)) << 4);
   }
 
   f32x4 acc[4][MI];  // [ni][mi]
@@ -683,7 +728,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
 #pragma unroll
       for (int wi = mi * 4 / MI; wi < (mi + 1) * 4 / MI; ++wi)
-        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + wi * W_NI_STRIDE);
+        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + w_ni_off(wi));
       if constexpr (DMA) {
 #pragma unroll
         for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
@@ -704,7 +749,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + i * W_NI_STRIDE);
+  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + w_ni_off(i));
 #pragma unroll
   for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
   int st = 0;  // LDS stage of the current K step
@@ -777,7 +822,7 @@ __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((
 
 template <int EPI, int ALOAD, bool SF32>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams p) {
-  constexpr bool NAT = nat_order(EPI, SF32);   // natural W-row / column order for fp32-stream epilogues
+  constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -795,7 +840,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     xs[i].init(p, m, pch ^ key_x(row));
-    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ (NAT ? key_x(row) : key_w(row))) * 8;
+    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8;
   }
   auto stage = [&](int kt, int buf) {
     char* sx = smem + buf * STAGE_BYTES;
@@ -816,8 +861,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
   for (int i = 0; i < 4; ++i) {
     const int xr = wm * 64 + i * 16 + l15;
     xoff[i] = xr * 128; xkey[i] = key_x(xr);
-    const int wr = wn * 64 + w_frag_row<NAT>(l15, i);
-    woff[i] = wr * 128; wkey[i] = NAT ? key_x(wr) : key_w(wr);
+    const int wr = wn * 64 + w_frag_row<MAP>(l15, i);
+    woff[i] = wr * 128; wkey[i] = w_key<MAP>(wr);
   }
 
   f32x4 acc[4][4];  // [ni][mi]

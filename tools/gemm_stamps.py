@@ -8,7 +8,7 @@ import numpy as np, torch
 from rajni_amd import ops, _native as nat
 dev = "cuda"
 for name, M, N, K, epi in [("qkv", 50432, 2304, 768, nat.EPI_BIAS), ("fc1", 50432, 3072, 768, nat.EPI_BIAS_GELU),
-                           ("fc2", 50432, 768, 3072, nat.EPI_BIAS_RESID), ("l2fit", 8192, 1024, 768, nat.EPI_BIAS)]:
+                           ("l2fit", 8192, 2048, 768, nat.EPI_BIAS)]:
     x = torch.randn(1, M, K, device=dev).to(torch.bfloat16)
     w = ops.pack_weight((torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16))
     b = torch.randn(N, device=dev)
