@@ -112,7 +112,8 @@ typedef struct {
   int stream_f32;  /* RESID only: resid and y are the fp32 residual stream (1) instead of `dtype` (0) */
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
-/* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 2-stage, 2 = 256x128x32 pipelined, 3 = 128x128x32 pipelined, 4 = 256x256x64 persistent, 5 = 256x128x64 3-stage persistent */
+/* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 (4 waves), 4 = 256x256x64 persistent,
+ * 5 = 256x128x64 3-stage persistent */
 void rajni_debug_force_gemm_tiling(int mode);
 /* diagnostic builds (-DRAJNI_GEMM_STAMPS) only: device buffer receiving 4 x uint64 s_memtime stamps per
  * workgroup of the 256x256 GEMM (start, main loop start, main loop end, end); NULL disables */

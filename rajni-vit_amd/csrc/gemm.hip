@@ -15,10 +15,12 @@
 //     tile row is fetched from HBM once per XCD and W stays L2-resident.
 //
 // Tilings (chosen per launch, see launch_gemm):
-//   pipe<8> 256(M) x 128(N) x 32(K), 4 waves each owning 128x64, 3 LDS stages (72 KiB, 2 workgroups
-//           per CU), register-double-buffered fragments, LDS reads + LDS-DMA interleaved with MFMAs;
-//   pipe<4> 128 x 128 x 32, same pipeline, wave tile 64x64 (48 KiB, 3 workgroups per CU);
-//   small   128 x 128 x 64, 2 stages, one barrier + drain per step - for M < 1024 (head, tiny batches).
+//   wide  256 x 256 x 64, 8 waves, 2 LDS stages, persistent stream  - wide outputs (qkv, fc1)
+//   mid   256 x 128 x 64, 8 waves, 3 LDS stages, persistent stream  - N = 768-class outputs (proj, fc2)
+//   small 128 x 128 x 64, 4 waves, 2 stages, 2 workgroups per CU    - M < 1024 (head, tiny batches)
+//   f32   128 x 128 x 32(fp32) on v_mfma_f32_16x16x4_f32            - fp32 models
+// (Two further tilings, 256x128x32 and 128x128x32 with 3 stages of 64-byte rows, were built and
+//  measured in round 1 and removed: half-line DMA pieces made them slower than `small` on every shape.)
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -195,7 +197,6 @@ constexpr bool nat_order(int epi, bool sf32) { return sf32 && (epi == EPI_RESID 
 //            and the 4 lanes of a row write one whole 64-byte sector per 16-byte store instruction.
 //            (With 16 consecutive columns per lane every store instruction wrote 4 quarter sectors
 //            per row: the wide tiling's epilogue took 9.5k cycles per 256x256 tile, store-issue bound.)
-//   MAP_P16  col = 16*g + 4*ni + rg          16 consecutive columns per lane (pipe tilings only)
 enum { MAP_P16 = 0, MAP_NAT = 1, MAP_SEC = 2 };
 constexpr int col_map(int epi, bool sf32) { return nat_order(epi, sf32) ? MAP_NAT : MAP_SEC; }
 
@@ -373,216 +374,6 @@ struct XSource {
     return base + ((long)ch * p.S + ky) * p.S + kx;
   }
 };
-
-// =============================================================================================
-// pipelined tiling: (32*MI)(M) x 128(N) x 32(K), 3 LDS stages, fragments double-buffered in registers
-//   MI = 8: 256 x 128 tile, wave tile 128 x 64 (72 KiB LDS, 2 workgroups per CU)
-//   MI = 4: 128 x 128 tile, wave tile  64 x 64 (48 KiB LDS, 3 workgroups per CU) - used when the
-//           256-row tiling would leave most CUs idle in its last round (N = 768 outputs)
-// Per K step a wave issues, INTERLEAVED between its MFMAs (sched_group_barrier): the LDS reads of
-// the NEXT step's fragments into the other register set and the LDS-DMA pieces of the step three
-// ahead.  One raw s_barrier per step; DMA completion by counted vmcnt (never 0 in the main loop).
-// =============================================================================================
-namespace pipe {
-constexpr int BN = 128, BK = 32, STAGES = 3;
-constexpr int W_BYTES = BN * BK * 2;            //  8 KiB
-// 64-byte rows: 4 rows per 256-byte bank row, slot = (row&3)*4 + (chunk ^ key).  The 16 rows of one
-// ds_read_b128 lane group come as {4 rows @chunk c} u {4 rows @c} u {8 rows @c^1}; the keys below
-// make the 16 slots distinct (derivation in DESIGN.md "LDS swizzles").
-__device__ __forceinline__ int key_x(int row) { return (-(row >> 2)) & 3; }   // natural rows base + (lane&15)
-__device__ __forceinline__ int key_w(int row) { return (-(row >> 4)) & 3; }   // permuted rows 16a + 4ni + b
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12, "unsupported vmcnt");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-}
-
-// compile-time issue order of one K step: NG groups of {4 MFMAs, 1 X (+1 W in the first 4 groups)
-// fragment read of the next step, 1 DMA piece in the first DM groups}
-template <int G, int NG, bool READ, int DM>
-__device__ __forceinline__ void sched_steps() {
-  if constexpr (G < NG) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, G < 4 ? 2 : 1, 0);
-    if constexpr (G < DM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    sched_steps<G + 1, NG, READ, DM>();
-  }
-}
-
-template <int MI> struct Cfg {
-  static constexpr int BM = 32 * MI;
-  static constexpr int X_BYTES = BM * BK * 2;
-  static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
-  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-  static constexpr int XP = MI / 2;          // X pieces (1 KiB) per wave per K step
-  static constexpr int PIECES = XP + 2;      // + 2 W pieces
-};
-
-template <int EPI, int ALOAD, bool SF32, int MI>
-__global__ void __launch_bounds__(256, 2) gemm_bf16_tn_pipe(const GemmParams p) {
-  using C = Cfg<MI>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = xcd_tile(p.total_tiles);
-  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-  const int m0 = tm * C::BM, n0 = tn * BN;
-
-  // ---- staging: a piece = one wave instruction = 1 KiB = 16 rows x 64 B
-  const int r_in = lane >> 2, pos = lane & 3;
-  XSource<ALOAD> xs[C::XP];
-  const bf16_t* ws[2];
-#pragma unroll
-  for (int i = 0; i < C::XP; ++i) {
-    const int row = (wave * C::XP + i) * 16 + r_in;
-    int m = m0 + row;
-    if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
-    xs[i].init(p, m, pos ^ key_x(row));
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 16 + r_in;
-    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pos ^ key_w(row)) * 8;  // W rows padded to 128
-  }
-  auto stage = [&](int kt, int st) {
-    char* sx = smem + st * C::STAGE_BYTES;
-    char* sw = sx + C::X_BYTES;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < C::XP; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * C::XP + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 2 + i) * 1024), 16, 0, 0);
-  };
-
-  // ---- fragment read offsets (bytes inside a stage), K-step invariant
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  int xoff[MI], woff[4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int xr = wm * (16 * MI) + i * 16 + l15;
-    xoff[i] = xr * 64 + ((g ^ key_x(xr)) << 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int wr = wn * 64 + 16 * (l15 >> 2) + i * 4 + (l15 & 3);
-    woff[i] = C::X_BYTES + wr * 64 + ((g ^ key_w(wr)) << 4);
-  }
-
-  f32x4 acc[4][MI];  // [ni][mi]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto read_frags = [&](int st, bf16x8 (&xf)[MI], bf16x8 (&wf)[4]) {
-    const char* sb = smem + st * C::STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + woff[i]);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + xoff[i]);
-  };
-  auto mma = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[4]) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-  };
-  // One K step: compute tile kt from (xc,wc); meanwhile read tile kt+1 (stage st1) into (xn,wn_)
-  // and DMA tile kt+3 into the stage tile kt just vacated (st0).
-  //   ISSUE: tile kt+3 exists.  WAIT: pieces that may stay in flight while tile kt+1 must have landed
-  //   (-1: nothing to wait for).  READ: tile kt+1 exists.
-  auto phase = [&](auto issue_c, auto wait_c, auto read_c, bf16x8 (&xc)[MI], bf16x8 (&wc)[4],
-                   bf16x8 (&xn)[MI], bf16x8 (&wn_)[4], int kt, int st0, int st1) {
-    constexpr bool ISSUE = decltype(issue_c)::value;
-    constexpr int WAIT = decltype(wait_c)::value;
-    constexpr bool READ = decltype(read_c)::value;
-    if constexpr (READ) {
-      // my reads of tile kt (issued last step) are complete, my DMA pieces of tile kt+1 have landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<WAIT>();
-      __builtin_amdgcn_s_barrier();  // ... and so have everyone else's: tile kt+1 readable, stage st0 free
-      asm volatile("" ::: "memory");
-    }
-    if constexpr (ISSUE) stage(kt + 3, st0);
-    // Group mi: 4 MFMAs on xc[mi], then the read of xn[mi] - which may land in the registers xc[mi]
-    // just vacated, so one X fragment set + two W sets are live (~200 VGPRs, not 250) - plus one W
-    // fragment read (first 4 groups) and one DMA piece (first PIECES groups).
-    const char* sb = smem + st1 * C::STAGE_BYTES;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);
-      if constexpr (READ) {
-        xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xoff[mi]);
-        if (mi < 4) wn_[mi] = *reinterpret_cast<const bf16x8*>(sb + woff[mi]);
-      }
-    }
-    sched_steps<0, MI, READ, ISSUE ? C::PIECES : 0>();
-  };
-  using T = std::true_type; using F = std::false_type;
-  constexpr int PC = C::PIECES;
-
-  const int nk = p.K / BK;   // even, >= 2
-  bf16x8 xa[MI], wa[4], xb[MI], wb[4];
-  stage(0, 0);
-  stage(1, 1);
-  if (nk > 2) { stage(2, 2); wait_vmcnt<2 * PC>(); } else { wait_vmcnt<PC>(); }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  read_frags(0, xa, wa);
-  int st = 0;  // stage of tile kt
-  auto nxt = [](int s3) { return s3 == 2 ? 0 : s3 + 1; };
-  int kt = 0;
-  for (; kt < nk - 4; kt += 2) {
-    const int s1 = nxt(st), s2 = nxt(s1);
-    phase(T{}, std::integral_constant<int, PC>{}, T{}, xa, wa, xb, wb, kt, st, s1);
-    phase(T{}, std::integral_constant<int, PC>{}, T{}, xb, wb, xa, wa, kt + 1, s1, s2);
-    st = s2;
-  }
-  if (nk >= 4) {  // kt == nk - 4: tile kt+3 is the last one
-    const int s1 = nxt(st), s2 = nxt(s1);
-    phase(T{}, std::integral_constant<int, PC>{}, T{}, xa, wa, xb, wb, kt, st, s1);
-    phase(F{}, std::integral_constant<int, PC>{}, T{}, xb, wb, xa, wa, kt + 1, s1, s2);
-    st = s2;
-    kt += 2;
-  }
-  {  // kt == nk - 2
-    const int s1 = nxt(st);
-    phase(F{}, std::integral_constant<int, 0>{}, T{}, xa, wa, xb, wb, kt, st, s1);
-    phase(F{}, std::integral_constant<int, 0>{}, F{}, xb, wb, xa, wa, kt + 1, s1, st);
-  }
-
-  // ---- epilogue: lane owns row m and columns nb .. nb+15
-  const int nb = n0 + wn * 64 + 16 * g;
-  float bias[16], gam[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int n = nb + j;
-    bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-    gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
-  }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * (16 * MI) + mi * 16 + l15;
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-    epilogue_row<EPI, SF32>(p, m, nb, nb + 8, v, gam);
-  }
-}
-}  // namespace pipe
 
 // =============================================================================================
 // stream tilings: 256(M) x BN x 64(K), 8 waves, ONE persistent workgroup per CU that walks its tiles
@@ -1091,7 +882,7 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
 }
 
 int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
-int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stage), 2 pipe MI=8, 3 pipe MI=4, 4 wide 256x256x64, 5 mid 256x128x64 (tests)
+int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stages), 4 wide 256x256x64, 5 mid 256x128x64 (tests)
 
 // rounds of workgroups a launch needs on 256 CUs at `per_cu` resident workgroups each, weighted by
 // the tile's relative duration: picks the tiling that finishes first
@@ -1106,8 +897,8 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
-  if (mode == 4 && p.K < 192) mode = 2;   // the persistent streams need >= NS + 1 K steps
-  if (mode == 5 && p.K < 256) mode = 2;
+  if (mode == 4 && p.K < 192) mode = 1;   // the persistent streams need >= NS + 1 K steps
+  if (mode == 5 && p.K < 256) mode = 1;
   if (mode == 0) {
     // measured on ViT-B shapes (tools/gemm_bench.py, tools/proj_probe.py, profiles/):
     //   wide outputs (qkv, fc1): persistent 256x256 (950 / 870 TFLOP/s vs 750 / 700 for 128x128);
@@ -1118,7 +909,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     else if (p.M >= 1024 && p.K >= 256) mode = 5;
     else mode = 1;
   }
-  static bool attr[5] = {false, false, false, false, false};
+  static bool attr[5] = {false, false, false, false, false};   // [2] small, [3] wide, [4] mid
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
                  2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
   int rc;
@@ -1135,16 +926,6 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     p.total_tiles = t256;
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
-  } else if (mode == 2) {
-    constexpr int lds = pipe::Cfg<8>::LDS_BYTES;
-    if ((rc = set_lds_attr(&pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 8>, lds, attr[0])) != RAJNI_OK) return rc;
-    p.total_tiles = t256;
-    hipLaunchKernelGGL((pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 8>), dim3(t256), dim3(256), lds, s, p);
-  } else if (mode == 3) {
-    constexpr int lds = pipe::Cfg<4>::LDS_BYTES;
-    if ((rc = set_lds_attr(&pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 4>, lds, attr[1])) != RAJNI_OK) return rc;
-    p.total_tiles = t128;
-    hipLaunchKernelGGL((pipe::gemm_bf16_tn_pipe<EPI, ALOAD, SF32, 4>), dim3(t128), dim3(256), lds, s, p);
   } else {
     constexpr int lds = small::LDS_BYTES;
     if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32>, lds, attr[2])) != RAJNI_OK) return rc;

@@ -45,7 +45,7 @@ def test_device_is_gfx950():
 # GEMM + epilogues
 # ---------------------------------------------------------------------------------------------
 
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["t128x128x64", "t256x128x32", "t128x128x32", "t256x256x64", "t256x128x64s3"])
+@pytest.fixture(params=[1, 4, 5], ids=["small128x128", "wide256x256", "mid256x128"])
 def tiling(request):
     """Every GEMM tiling must give the same answers: force each one (rajni_debug_force_gemm_tiling)."""
     nat.lib().rajni_debug_force_gemm_tiling(request.param)

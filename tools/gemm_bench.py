@@ -11,7 +11,7 @@ dev = "cuda"
 shapes = [("qkv", 50432, 2304, 768, nat.EPI_BIAS), ("fc1", 50432, 3072, 768, nat.EPI_BIAS_GELU),
           ("proj", 50432, 768, 768, nat.EPI_BIAS_RESID), ("fc2", 50432, 768, 3072, nat.EPI_BIAS_RESID),
           ("fc2_87", 22272, 768, 3072, nat.EPI_BIAS_RESID), ("qkv_121", 30976, 2304, 768, nat.EPI_BIAS)]
-modes = [int(m) for m in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3".split(","))]
+modes = [int(m) for m in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,4,5".split(","))]
 rounds = 5
 res = {}
 for name, M, N, K, epi in shapes:
