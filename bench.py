@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--model", default="vit_base_patch16_224")
+    ap.add_argument("--weight-format", default="model", choices=["model", "fp8"],
+                    help='"fp8": block Linear weights as e4m3 + per-row scale (BASELINE configs[4]); the headline '
+                         'metric is quoted on "model" (bf16 weights)')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -136,6 +139,7 @@ def main():
     B = args.batch
     model = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev)
     wrapped = rajni_amd.RAJNIViTWrapper(model, schedule).eval()
+    wrapped.set_weight_format(args.weight_format)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=gen, device=dev).to(torch.bfloat16)
 
@@ -195,7 +199,8 @@ def main():
     out = {"metric": "images/sec ViT-B/16@224 with README schedule", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"{args.model} bf16, batch {B}/GPU, README 4-stage schedule "
+           "config": {"workload": f"{args.model} bf16{' activations, fp8 e4m3 block weights' if args.weight_format == 'fp8' else ''}, "
+                                  f"batch {B}/GPU, README 4-stage schedule "
                                   f"{{3:.88,4:.88,7:.80,8:.72}}, synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
                       "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}"},

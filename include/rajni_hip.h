@@ -110,6 +110,10 @@ typedef struct {
   int epilogue;
   int dtype;
   int stream_f32;  /* RESID only: resid and y are the fp32 residual stream (1) instead of `dtype` (0) */
+  /* fp8 weights (BASELINE config 5): when non-NULL, `w` holds fp8 e4m3 (OCP "fn": no inf, max 448) bytes
+   * [N(pad256),K], ldw in bytes and a multiple of 16, and w_scale[n] (fp32 [N]) is the dequantisation
+   * scale of row n: y = epi(x (q*s)^T) with bf16 x and fp32 accumulation.  dtype must be RAJNI_BF16. */
+  const float* w_scale;
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
 /* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 (4 waves), 4 = 256x256x64 persistent,
@@ -144,6 +148,8 @@ typedef struct {
   void* scores;            /* [B,N] out, dtype (optional) */
   void* next_scores;       /* [B,keep+1] out, dtype (required when keep>0: carried to the next block) */
   const int32_t* forced_keep_idx; /* test hook: use this selection instead (selection-conditional parity) */
+  /* per-row scales of fp8 e4m3 weights (see rajni_linear_args.w_scale); NULL = that weight is `dtype` */
+  const float* qkv_s; const float* proj_s; const float* fc1_s; const float* fc2_s;
 } rajni_block;
 
 typedef struct {

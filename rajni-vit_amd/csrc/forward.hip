@@ -97,7 +97,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (rc != RAJNI_OK) return rc;
     rajni_linear_args g{};
     g.dtype = dt;
-    g.x = w.xn; g.lda = C; g.w = blk.qkv_w; g.ldw = C; g.bias = blk.qkv_b;
+    g.x = w.xn; g.lda = C; g.w = blk.qkv_w; g.ldw = C; g.bias = blk.qkv_b; g.w_scale = blk.qkv_s;
     g.y = w.qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epilogue = RAJNI_EPI_BIAS;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
@@ -149,7 +149,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     const int Mp = B * Np;
     g = rajni_linear_args{};
     g.dtype = dt;
-    g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1;
+    g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1; g.w_scale = blk.proj_s;
     g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     if (idx) {
       g.r_idx = idx; g.r_np = Np; g.r_nsrc = N;
@@ -168,13 +168,13 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
     g.dtype = dt;
-    g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b;
+    g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b; g.w_scale = blk.fc1_s;
     g.y = w.hid; g.ldc = p.hidden; g.M = Mp; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
     g.dtype = dt;
-    g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2;
+    g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2; g.w_scale = blk.fc2_s;
     g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = Mp; g.N = C; g.K = p.hidden;
     g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     rc = launch_linear(g, s);

@@ -32,7 +32,8 @@ enum { ALOAD_PLAIN = 0, ALOAD_PATCH = 1 };
 
 struct GemmParams {
   const void* X; long lda;      // activations (bf16, or fp32 on the fp32 model path)
-  const void* W; long ldw;      // weights, same element type
+  const void* W; long ldw;      // weights, same element type (or fp8 e4m3 bytes, see wscale)
+  const float* wscale;          // W8 kernels: W is fp8 e4m3 [N,K] and wscale[n] its per-row dequantisation scale
   const float* bias;
   const float* gamma;
   const void* R; long ldr;      // residual stream rows (bf16 or fp32, see SF32)
@@ -223,6 +224,34 @@ __device__ __forceinline__ int w_key(int row) {
                         : ((row >> 4) & 3) * 2 + ((row >> 1) & 1);
 }
 
+// ---- fp8 (e4m3) weights: 64-byte tile rows (BK = 64 one-byte elements) -----------------------------
+// A W fragment of v_mfma_f32_16x16x32_bf16 is 8 consecutive k of one row = 8 BYTES here (ds_read_b64),
+// converted to bf16 in registers (v_cvt_scalef32_pk_bf16_fp8, exact); the per-row scale multiplies the
+// fp32 accumulator in the epilogue, so the arithmetic is x . (q * s) - a bf16 activation times the
+// DEQUANTISED weight - with fp32 accumulation.  LDS-DMA still moves 16-byte units, so the swizzle
+// works on the four 16-byte units of a row: a ds_read_b64 lane group (32 lanes: 16 rows x 2 halves)
+// is conflict free when the 4 rows of every (row % 4) class sit in 4 distinct units.
+template <int MAP>
+__device__ __forceinline__ int w_key8(int row) {
+  return MAP == MAP_NAT ? (row >> 2) & 3 : (row >> 3) & 3;
+}
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint2 raw) {
+  const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, false);
+  const bf16x2 b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, true);
+  const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, false);
+  const bf16x2 d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, true);
+  return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+// The 8 fp8 bytes are read from LDS through a __bf16 vector type ON PURPOSE: hipcc's waitcnt insertion
+// puts s_waitcnt vmcnt(0) in front of every LDS read that type-based alias analysis cannot separate
+// from the LDS-DMA writes - with a uint2 read each W fragment read drained the whole DMA queue (the
+// mid tiling ran at 390 instead of 840 TFLOP/s).  Reads typed like the bf16 fragments are left alone.
+typedef __attribute__((ext_vector_type(4))) __bf16 fp8x8_raw;
+template <bool W8> struct WFragT { typedef bf16x8 type; };
+template <> struct WFragT<true> { typedef fp8x8_raw type; };
+__device__ __forceinline__ bf16x8 w_frag_bf16(const bf16x8& f) { return f; }
+__device__ __forceinline__ bf16x8 w_frag_bf16(const fp8x8_raw& f) { return fp8x8_to_bf16(__builtin_bit_cast(uint2, f)); }
+
 // natural-order epilogue of one output row (fp32 stream): v = accumulators + bias on entry
 template <int EPI>
 __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int n0w, int g, float* v, const float* gam) {
@@ -299,8 +328,8 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 }
 
 // shared tail of every bf16 tiling: bias/gamma for this lane's columns, then one row per m-tile
-template <int EPI, bool SF32, int MI>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (&acc)[4][MI], int m_base, int n0w,
+template <int EPI, bool SF32, int MI, bool W8 = false>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n0w,
                                               int l15, int g, const ResidPrefetch<MI>& pre) {
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
@@ -310,6 +339,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x4 (
     const int n = out_col<MAP>(n0w, g, j);
     bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
     gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
+  }
+  if constexpr (W8) {   // dequantise: accumulator column n times the scale of W row n
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = out_col<MAP>(n0w, g, j);
+      const float sc = n < p.N ? p.wscale[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[j >> 2][mi][j & 3] *= sc;
+    }
   }
   if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
     if (pre.valid) {   // interior tile whose residual rows were prefetched during the last K step
@@ -406,12 +444,13 @@ constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
 
-template <int WN_, int NS_> struct Cfg {
+template <int WN_, int NS_, bool W8_ = false> struct Cfg {
   static constexpr int BN = WN_ * 64;
-  static constexpr int W_BYTES = BN * BK * 2;
+  static constexpr int WB = W8_ ? 1 : 2;         // bytes per W element
+  static constexpr int W_BYTES = BN * BK * WB;
   static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
   static constexpr int LDS_BYTES = NS_ * STAGE_BYTES;
-  static constexpr int PW = BN / 64;             // W pieces (1 KiB) per wave per K step
+  static constexpr int PW = W_BYTES / 8192;      // W pieces (1 KiB) per wave per K step
   static constexpr int PIECES = 4 + PW;          // + 4 X pieces
 };
 
@@ -439,17 +478,19 @@ __device__ __forceinline__ void sched_half() {
   }
 }
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
-  static_assert(N == 0 || N == 1 || N == 6 || N == 7 || N == 8, "unsupported vmcnt");
+  static_assert(N == 0 || N == 1 || N == 5 || N == 6 || N == 7 || N == 8, "unsupported vmcnt");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   else if (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
   else if (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
   else if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 }
 
-template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS>
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false>
 __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p) {
-  using C = Cfg<WN, NS>;
+  using C = Cfg<WN, NS, W8>;
+  using WFrag = typename WFragT<W8>::type;   // a W fragment as it sits in LDS: 8 bf16, or 8 fp8 bytes
   constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
   static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -457,9 +498,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
+  //      (fp8 W: a piece = 16 rows x 64 B, lane -> row lane>>2, 16-byte unit lane&3)
   const int r_in = lane >> 3, pch = lane & 7;
   XSource<ALOAD> xs[4];
-  const bf16_t* ws[C::PW];
+  const char* ws[C::PW];
   auto point_at = [&](int tile) {   // DMA source pointers of a tile
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
 #pragma unroll
@@ -471,15 +513,20 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     }
 #pragma unroll
     for (int i = 0; i < C::PW; ++i) {
-      const int row = (wave * C::PW + i) * 8 + r_in;
-      ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8;
+      if constexpr (W8) {
+        const int row = (wave * C::PW + i) * 16 + (lane >> 2);
+        ws[i] = reinterpret_cast<const char*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (((lane & 3) ^ w_key8<MAP>(row)) << 4);
+      } else {
+        const int row = (wave * C::PW + i) * 8 + r_in;
+        ws[i] = reinterpret_cast<const char*>(p.W) + ((long)(tn * C::BN + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8) * 2;
+      }
     }
   };
   auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
     if (q < 4)
       __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
     else
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[q - 4] + k0), LDS_PTR(dx + X_BYTES + (wave * C::PW + q - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[q - 4] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + q - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
   };
   auto stage = [&](int kt, int st) {
 #pragma unroll
@@ -493,33 +540,39 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int xr0 = wm * (MI * 16) + l15;
   const int wr0 = wn * 64 + w_frag_row<MAP>(l15, 0);
   // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same)
-  auto w_ni_off = [](int ni) { return (w_frag_row<MAP>(0, ni) - w_frag_row<MAP>(0, 0)) * 128; };
+  auto w_ni_off = [](int ni) { return (w_frag_row<MAP>(0, ni) - w_frag_row<MAP>(0, 0)) * (64 * C::WB); };
   int xo[2], wo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     xo[ks] = xr0 * 128 + (((ks * 4 + g) ^ key_x(xr0)) << 4);
-    wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ w_key<MAP>(wr0)) << 4);
+    if constexpr (W8)   // 8-byte fragment ks*4+g = half (g&1) of 16-byte unit (ks*4+g)>>1
+      wo[ks] = X_BYTES + wr0 * 64 + ((((ks * 4 + g) >> 1) ^ w_key8<MAP>(wr0)) << 4) + ((g & 1) << 3);
+    else
+      wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ w_key<MAP>(wr0)) << 4);
   }
 
   f32x4 acc[4][MI];  // [ni][mi]
 
   // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
   // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage dst
-  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], bf16x8 (&wc)[4], bf16x8 (&xn)[MI], bf16x8 (&wn_)[4],
+  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], WFrag (&wc)[4], bf16x8 (&xn)[MI], WFrag (&wn_)[4],
                   int rst, int rks, int dkt, int dst) {
     constexpr bool DMA = decltype(dma_c)::value;
     const char* sb = smem + rst * C::STAGE_BYTES;
     char* dx = smem + dst * C::STAGE_BYTES;
     const int k0 = dkt * BK;
+    bf16x8 wv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wv[ni] = w_frag_bf16(wc[ni]);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ni], xc[mi], acc[ni][mi], 0, 0, 0);
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
 #pragma unroll
       for (int wi = mi * 4 / MI; wi < (mi + 1) * 4 / MI; ++wi)
-        wn_[wi] = *reinterpret_cast<const bf16x8*>(sb + wo[rks] + w_ni_off(wi));
+        wn_[wi] = *reinterpret_cast<const WFrag*>(sb + wo[rks] + w_ni_off(wi));
       if constexpr (DMA) {
 #pragma unroll
         for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
@@ -532,15 +585,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int nk = p.K / BK;        // >= NS + 1 (host checked)
   int v = blockIdx.x;
   int tile = xcd_tile_of(v, p.total_tiles);
-  bf16x8 xa[MI], wa[4], xb[MI], wb[4];
+  bf16x8 xa[MI], xb[MI];
+  WFrag wa[4], wb[4];
   point_at(tile);
 #pragma unroll
   for (int j = 0; j < NS; ++j) stage(j, j);
-  wait_step<(NS - 1) * C::PIECES == 12 ? 0 : (NS - 1) * C::PIECES>();   // step 0 landed (NS=3: drain all)
+  wait_step<((NS - 1) * C::PIECES > 8) ? 0 : (NS - 1) * C::PIECES>();   // step 0 landed (NS=3: drain all)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(smem + wo[0] + w_ni_off(i));
+  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const WFrag*>(smem + wo[0] + w_ni_off(i));
 #pragma unroll
   for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
   int st = 0;  // LDS stage of the current K step
@@ -581,7 +635,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -611,9 +665,11 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // double buffered: 64 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
 
-template <int EPI, int ALOAD, bool SF32>
+template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams p) {
   constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
+  constexpr int PW = W8 ? 2 : 4;               // W pieces per wave per K step (fp8 tile is 8 KiB)
+  using WFrag = typename WFragT<W8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -624,14 +680,23 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
   // ---- staging: wave w stages pieces 4w..4w+3 of each operand; a piece = 8 rows x 128 B
   const int r_in = lane >> 3, pch = lane & 7;
   XSource<ALOAD> xs[4];
-  const bf16_t* ws[4];
+  const char* ws[PW];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + r_in;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     xs[i].init(p, m, pch ^ key_x(row));
-    ws[i] = reinterpret_cast<const bf16_t*>(p.W) + (long)(n0 + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    if constexpr (W8) {
+      const int row = (wave * PW + i) * 16 + (lane >> 2);
+      ws[i] = reinterpret_cast<const char*>(p.W) + (long)(n0 + row) * p.ldw + (((lane & 3) ^ w_key8<MAP>(row)) << 4);
+    } else {
+      const int row = (wave * PW + i) * 8 + r_in;
+      ws[i] = reinterpret_cast<const char*>(p.W) + ((long)(n0 + row) * p.ldw + (pch ^ w_key<MAP>(row)) * 8) * 2;
+    }
   }
   auto stage = [&](int kt, int buf) {
     char* sx = smem + buf * STAGE_BYTES;
@@ -641,8 +706,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds(GLB_PTR(xs[i].at(p, k0)), LDS_PTR(sx + (wave * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0), LDS_PTR(sw + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < PW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0 * (W8 ? 1 : 2)), LDS_PTR(sw + (wave * PW + i) * 1024), 16, 0, 0);
   };
 
   const int wm = wave >> 1, wn = wave & 1;
@@ -653,7 +718,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     const int xr = wm * 64 + i * 16 + l15;
     xoff[i] = xr * 128; xkey[i] = key_x(xr);
     const int wr = wn * 64 + w_frag_row<MAP>(l15, i);
-    woff[i] = wr * 128; wkey[i] = w_key<MAP>(wr);
+    woff[i] = wr * (W8 ? 64 : 128); wkey[i] = W8 ? w_key8<MAP>(wr) : w_key<MAP>(wr);
   }
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -680,7 +745,10 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         xf[i] = *reinterpret_cast<const bf16x8*>(sx + xoff[i] + ((c ^ xkey[i]) << 4));
-        wf[i] = *reinterpret_cast<const bf16x8*>(sw + woff[i] + ((c ^ wkey[i]) << 4));
+        if constexpr (W8)
+          wf[i] = w_frag_bf16(*reinterpret_cast<const WFrag*>(sw + woff[i] + (((c >> 1) ^ wkey[i]) << 4) + ((c & 1) << 3)));
+        else
+          wf[i] = *reinterpret_cast<const bf16x8*>(sw + woff[i] + ((c ^ wkey[i]) << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
@@ -690,7 +758,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     }
   }
 
-  epilogue_tile<EPI, SF32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g, pre);
+  epilogue_tile<EPI, SF32, 4, W8>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g, pre);
 }
 }  // namespace small
 
@@ -881,6 +949,11 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
   store1<SF32>(x, (long)b * img_stride + c, v);
 }
 
+// LDS stages of the wide tiling: 2 for bf16 weights (2 x 64 KiB); fp8 weights leave room for 3 (3 x 48 KiB)
+#ifndef RAJNI_W8_WIDE_NS
+#define RAJNI_W8_WIDE_NS 2
+#endif
+#define RAJNI_W8_WIDE_NS_OR(w8) ((w8) ? RAJNI_W8_WIDE_NS : 2)
 int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
 int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stages), 4 wide 256x256x64, 5 mid 256x128x64 (tests)
 
@@ -891,7 +964,7 @@ inline double launch_cost(int tiles, int per_cu, double tile_time) {
   return ((tiles + slots - 1) / slots) * tile_time;
 }
 
-template <int EPI, int ALOAD, bool SF32>
+template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.stamps = rajni_g_stamps;
   p.tiles_n = (p.N + 127) / 128;
@@ -911,26 +984,27 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   }
   static bool attr[5] = {false, false, false, false, false};   // [2] small, [3] wide, [4] mid
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
-                 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
+                 2.0 * ((double)p.M * p.K + (double)p.M * p.N) + (W8 ? 1.0 : 2.0) * (double)p.N * p.K);
   int rc;
   if (mode == 4) {
-    using C = wide::Cfg<4, 2>;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, 2>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
+    using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
+    constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, 2>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else if (mode == 5) {
-    using C = wide::Cfg<2, 3>;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+    using C = wide::Cfg<2, 3, W8>;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
-    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {
     constexpr int lds = small::LDS_BYTES;
-    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32>, lds, attr[2])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>, lds, attr[2])) != RAJNI_OK) return rc;
     p.total_tiles = t128;
-    hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32>), dim3(t128), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>), dim3(t128), dim3(256), lds, s, p);
   }
   RAJNI_CHECK_LAUNCH("gemm_bf16_tn");
   return RAJNI_OK;
@@ -959,6 +1033,23 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   p.ridx = a.r_idx; p.r_np = a.r_np > 0 ? a.r_np : 1; p.r_nsrc = a.r_nsrc;
   p.Y = a.y; p.ldc = a.ldc;
   p.M = a.M; p.N = a.N; p.K = a.K;
+  p.wscale = a.w_scale;
+  if (a.w_scale != nullptr) {   // fp8 e4m3 weights, bf16 activations
+    RAJNI_REQUIRE(a.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_linear: fp8 weights need bf16 activations");
+    RAJNI_REQUIRE(a.ldw % 16 == 0, RAJNI_ERR_INVALID, "rajni_linear: fp8 weights need ldw %% 16 == 0");
+    switch (a.epilogue) {
+      case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN, false, true>(p, KC_GEMM_BIAS, s);
+      case RAJNI_EPI_BIAS_GELU: return launch_gemm<EPI_GELU, ALOAD_PLAIN, false, true>(p, KC_GEMM_GELU, s);
+      case RAJNI_EPI_BIAS_RESID:
+        RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0, RAJNI_ERR_INVALID,
+                      "rajni_linear: RESID epilogue needs resid and ldr %% 8 == 0");
+        return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true, true>(p, KC_GEMM_RESID, s)
+                            : launch_gemm<EPI_RESID, ALOAD_PLAIN, false, true>(p, KC_GEMM_RESID, s);
+      default:
+        rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
+        return RAJNI_ERR_INVALID;
+    }
+  }
   if (a.dtype == RAJNI_F32) {
     switch (a.epilogue) {
       case RAJNI_EPI_BIAS: return f32::launch<EPI_BIAS, ALOAD_PLAIN>(p, KC_GEMM_BIAS, s);

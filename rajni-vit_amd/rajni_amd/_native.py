@@ -30,7 +30,7 @@ class LinearArgs(C.Structure):
                 ("bias", c_void_p), ("gamma", c_void_p), ("resid", c_void_p), ("ldr", c_long),
                 ("r_idx", c_void_p), ("r_np", c_int), ("r_nsrc", c_int),
                 ("y", c_void_p), ("ldc", c_long), ("M", c_int), ("N", c_int), ("K", c_int),
-                ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int)]
+                ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int), ("w_scale", c_void_p)]
 
 
 class Block(C.Structure):
@@ -42,7 +42,8 @@ class Block(C.Structure):
                 ("fc2_w", c_void_p), ("fc2_b", c_void_p), ("ls2", c_void_p),
                 ("keep", c_int), ("update", c_int),
                 ("keep_idx", c_void_p), ("scores", c_void_p), ("next_scores", c_void_p),
-                ("forced_keep_idx", c_void_p)]
+                ("forced_keep_idx", c_void_p),
+                ("qkv_s", c_void_p), ("proj_s", c_void_p), ("fc1_s", c_void_p), ("fc2_s", c_void_p)]
 
 
 class VitPlan(C.Structure):

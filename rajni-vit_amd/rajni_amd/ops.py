@@ -33,6 +33,41 @@ def pack_weight(w: torch.Tensor, dtype=torch.bfloat16, device=None) -> torch.Ten
     return out
 
 
+FP8_E4M3_MAX = 448.0   # largest finite e4m3 "fn" value (OCP fp8: no infinities, one NaN pattern)
+
+
+def quantize_rows_fp8(w: torch.Tensor):
+    """Per-output-row symmetric fp8 e4m3 quantisation of a [N, K] weight held in the model dtype:
+    scale[n] = max|w[n,:]| / 448 (1 for an all-zero row), q = round-to-nearest-even(w / scale) in e4m3.
+    Returns (q as torch.float8_e4m3fn [N, K], scale fp32 [N]).  Host-side; runs wherever `w` lives."""
+    w32 = w.detach().to(torch.float32)
+    amax = w32.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_E4M3_MAX, torch.ones_like(amax))
+    q = (w32 / scale[:, None]).clamp_(-FP8_E4M3_MAX, FP8_E4M3_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def pack_weight_fp8(w: torch.Tensor, model_dtype=torch.bfloat16, device=None):
+    """[N, K...] Linear weight -> (uint8 [ceil256(N), K] of e4m3 bytes with zero padded rows, fp32 scale [N]).
+    The weight is first rounded to `model_dtype` (what the reference model would hold), then quantised."""
+    n = w.shape[0]
+    w2 = w.detach().reshape(n, -1).to(model_dtype)
+    if w2.shape[1] % 16 != 0:
+        raise ValueError("fp8 weights need the input dimension to be a multiple of 16")
+    q, scale = quantize_rows_fp8(w2)
+    dev = device if device is not None else w.device
+    npad = (n + 255) // 256 * 256
+    out = torch.zeros((npad, w2.shape[1]), dtype=torch.uint8, device=dev)
+    out[:n].copy_(q.view(torch.uint8))
+    return out, scale.to(dev).contiguous()
+
+
+def dequantize_fp8(q_packed: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """fp32 [N, K] weight the fp8 kernels multiply by: e4m3 value x row scale (the oracle side of parity tests)."""
+    n = scale.shape[0]
+    return q_packed[:n].view(torch.float8_e4m3fn).to(torch.float32) * scale.to(torch.float32)[:, None]
+
+
 def pack_vec(v: Optional[torch.Tensor], like_dtype=torch.bfloat16, device=None) -> Optional[torch.Tensor]:
     """bias / LayerNorm / LayerScale vector -> fp32 copy of the value the model dtype holds."""
     if v is None:
@@ -130,8 +165,9 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, row
 def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None,
            epilogue: int = nat.EPI_BIAS, gamma: Optional[torch.Tensor] = None,
            resid: Optional[torch.Tensor] = None, r_idx: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x @ W^T): x [..., K]; w_packed from pack_weight(); bias/gamma fp32 [n_out].
+    With `w_scale` (fp32 [n_out]) w_packed is the uint8 e4m3 tensor of pack_weight_fp8() and x is bf16.
     resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID; an fp32
     resid selects the fp32 residual stream (the output is then fp32 too)."""
     nat.require_device(x, "x")
@@ -144,7 +180,9 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
         out = torch.empty((M, ld), dtype=torch.float32 if stream_f32 else x.dtype, device=x.device)
     a = nat.LinearArgs()
     a.x, a.lda, a.w, a.ldw = x.data_ptr(), K, w_packed.data_ptr(), w_packed.shape[1]
-    a.bias, a.gamma = nat.ptr(bias), nat.ptr(gamma)
+    a.bias, a.gamma, a.w_scale = nat.ptr(bias), nat.ptr(gamma), nat.ptr(w_scale)
+    if w_scale is not None and w_packed.dtype != torch.uint8:
+        raise ValueError("w_scale given but w_packed is not the uint8 tensor of pack_weight_fp8()")
     a.y, a.ldc = out.data_ptr(), out.shape[-1] if out.dim() == 2 else out.stride(-2)
     a.M, a.N, a.K, a.epilogue, a.dtype, a.stream_f32 = M, n_out, K, epilogue, _dt(x), stream_f32
     if resid is not None:

@@ -71,6 +71,9 @@ class RAJNIViTWrapper(nn.Module):
         # residual stream precision between blocks: fp32 (default; see DESIGN.md "numerics") or the
         # model dtype like the reference's bf16 model (`set_residual_dtype(torch.bfloat16)`)
         self._resid_bf16 = False
+        # storage format of the four big Linear weights of every block: "model" = the model dtype,
+        # "fp8" = e4m3 bytes + per-row fp32 scale (`set_weight_format("fp8")`, bf16 models only)
+        self._weight_format = "model"
 
     # ------------------------------------------------------------------------------------------
     def get_last_stats(self):
@@ -106,6 +109,29 @@ class RAJNIViTWrapper(nn.Module):
         self._resid_bf16 = dtype == torch.bfloat16
         self._drop_plans()
         return self
+
+    def set_weight_format(self, fmt: str):
+        """"model" (default) or "fp8": keep qkv/proj/fc1/fc2 weights as fp8 e4m3 with one fp32 scale per
+        output row (BASELINE config 5).  Activations, accumulation, patch-embed and
+        head stay as they are; results equal the same model run with the DEQUANTISED weights."""
+        if fmt not in ("model", "fp8"):
+            raise ValueError('weight format must be "model" or "fp8"')
+        if fmt != self._weight_format:
+            self._weight_format = fmt
+            self._weights = self._weights_key = None
+            self._drop_plans()
+        return self
+
+    def dequantized_state_dict(self):
+        """fp32 copies of the block Linear weights as the fp8 kernels see them (q * scale), keyed like the
+        base model's state_dict.  Test surface: feed these to the oracle for the fp8 parity check."""
+        if self._weights is None or self._weight_format != "fp8":
+            raise RuntimeError("run a forward with set_weight_format('fp8') first")
+        out = {}
+        for i, bw in enumerate(self._weights["blocks"]):
+            for ours, theirs in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                out[f"blocks.{i}.{theirs}.weight"] = ops.dequantize_fp8(bw[ours + "_w"], bw[ours + "_s"])
+        return out
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
@@ -163,12 +189,17 @@ class RAJNIViTWrapper(nn.Module):
 
     def _pack_weights(self, device, dtype):
         params = self._all_params()
-        key = (str(device), dtype) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), dtype, self._weight_format) + tuple((p.data_ptr(), p._version) for p in params)
         if self._weights_key == key:
             return self._weights
         desc = self._describe()
         m = self.m
+        fp8 = self._weight_format == "fp8"
+        if fp8 and dtype != torch.bfloat16:
+            raise NotImplementedError("fp8 weights need a bf16 model (activations stay bf16)")
         pw = lambda w: ops.pack_weight(w, dtype, device)
+        # block Linear weight -> (packed tensor, per-row scale or None)
+        pq = (lambda w: ops.pack_weight_fp8(w, dtype, device)) if fp8 else (lambda w: (pw(w), None))
         pv = lambda v: ops.pack_vec(v, dtype, device)
         zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
         W = dict(desc=desc)
@@ -192,13 +223,15 @@ class RAJNIViTWrapper(nn.Module):
             for dp in (getattr(blk, "drop_path1", None), getattr(blk, "drop_path2", None)):
                 if dp is not None and not isinstance(dp, nn.Identity) and self.training:
                     raise NotImplementedError("drop_path in training mode: this is the inference path")
+            (qkv_w, qkv_s), (proj_w, proj_s) = pq(a.qkv.weight), pq(a.proj.weight)
+            (fc1_w, fc1_s), (fc2_w, fc2_s) = pq(blk.mlp.fc1.weight), pq(blk.mlp.fc2.weight)
             blocks.append(dict(
                 norm1_w=pv(blk.norm1.weight), norm1_b=pv(blk.norm1.bias),
-                qkv_w=pw(a.qkv.weight), qkv_b=pv(a.qkv.bias) if a.qkv.bias is not None else zeros(3 * desc["C"]),
-                proj_w=pw(a.proj.weight), proj_b=pv(a.proj.bias) if a.proj.bias is not None else zeros(desc["C"]),
+                qkv_w=qkv_w, qkv_s=qkv_s, qkv_b=pv(a.qkv.bias) if a.qkv.bias is not None else zeros(3 * desc["C"]),
+                proj_w=proj_w, proj_s=proj_s, proj_b=pv(a.proj.bias) if a.proj.bias is not None else zeros(desc["C"]),
                 ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
-                fc1_w=pw(blk.mlp.fc1.weight), fc1_b=pv(blk.mlp.fc1.bias),
-                fc2_w=pw(blk.mlp.fc2.weight), fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
+                fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=pv(blk.mlp.fc1.bias),
+                fc2_w=fc2_w, fc2_s=fc2_s, fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
         self._drop_plans()
@@ -230,7 +263,7 @@ class RAJNIViTWrapper(nn.Module):
         for i, bw in enumerate(W["blocks"]):
             cb = blocks[i]
             for name in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
-                         "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2"):
+                         "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s"):
                 setattr(cb, name, nat.ptr(bw[name]))
             if i in self.pruning_schedule:
                 cfg = self.pruning_schedule[i]

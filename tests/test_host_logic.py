@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert set(nat.EXPORTED_SYMBOLS) == declared
-    assert lib.rajni_abi_version() == 1
+    assert lib.rajni_abi_version() == 2
     assert lib.rajni_profile_class_name(0).decode().startswith("gemm")
 
 
@@ -199,3 +199,30 @@ def test_cli_flags_match_reference_and_schedule_loader(tmp_path):
     f.write_text('{"3": {"keep_ratio": 0.95, "update": false}, "4": {"keep_ratio": 0.95}}')
     assert run.load_schedule(str(f)) == {3: {"keep_ratio": 0.95, "update": False}, 4: {"keep_ratio": 0.95}}
     assert run.load_schedule(None) == run.README_SCHEDULE
+
+
+def test_fp8_row_quantiser_properties():
+    """ops.quantize_rows_fp8 / pack_weight_fp8 (host side of the fp8-weight path): per-row
+    scale maps the row maximum onto +-448, zero rows are harmless, RNE error bound, padded layout."""
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((37, 64)).astype(np.float32) * rng.uniform(0.01, 5.0, size=(37, 1)).astype(np.float32)
+    w[5] = 0.0
+    wt = torch.from_numpy(w).to(torch.bfloat16)
+    q, scale = ops.quantize_rows_fp8(wt)
+    assert q.dtype == torch.float8_e4m3fn and scale.dtype == torch.float32 and tuple(scale.shape) == (37,)
+    qf = q.to(torch.float32)
+    assert torch.isfinite(qf).all()
+    rows = [i for i in range(37) if i != 5]
+    assert (qf[rows].abs().amax(dim=1) == ops.FP8_E4M3_MAX).all()
+    assert scale[5] == 1.0 and (qf[5] == 0).all()
+    deq = qf * scale[:, None]
+    ref = wt.to(torch.float32)
+    # normal range: relative error <= 2^-4; below the smallest normal (2^-6 * scale) absolute error <= 2^-10 * scale
+    bound = torch.maximum(ref.abs() * 2.0 ** -4, scale[:, None] * 2.0 ** -10) * 1.0001
+    assert (deq - ref).abs().le(bound).all()
+    packed, s2 = ops.pack_weight_fp8(torch.from_numpy(w), torch.bfloat16, "cpu")
+    assert packed.dtype == torch.uint8 and tuple(packed.shape) == (256, 64) and torch.equal(s2, scale)
+    assert (packed[37:] == 0).all() and torch.equal(packed[:37], q.view(torch.uint8))
+    assert torch.equal(ops.dequantize_fp8(packed, s2), deq)
+    with pytest.raises(ValueError):
+        ops.pack_weight_fp8(torch.zeros(4, 24), torch.bfloat16, "cpu")

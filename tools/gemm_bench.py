@@ -12,11 +12,13 @@ shapes = [("qkv", 50432, 2304, 768, nat.EPI_BIAS), ("fc1", 50432, 3072, 768, nat
           ("proj", 50432, 768, 768, nat.EPI_BIAS_RESID), ("fc2", 50432, 768, 3072, nat.EPI_BIAS_RESID),
           ("fc2_87", 22272, 768, 3072, nat.EPI_BIAS_RESID), ("qkv_121", 30976, 2304, 768, nat.EPI_BIAS)]
 modes = [int(m) for m in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,4,5".split(","))]
+FP8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"   # second argument "fp8": e4m3 weights + per-row scale
 rounds = 5
 res = {}
 for name, M, N, K, epi in shapes:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
-    w = ops.pack_weight((torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16))
+    w, wsc = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16), None
+    w, wsc = ops.pack_weight_fp8(w, torch.bfloat16, dev) if FP8 else (ops.pack_weight(w), None)
     b = torch.randn(N, device=dev)
     resid = torch.randn(1, M, N, device=dev) if epi == nat.EPI_BIAS_RESID else None
     out = None
@@ -27,7 +29,7 @@ for name, M, N, K, epi in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                y = ops.linear(x.view(1, M, K), w, N, b, epi, resid=resid)
+                y = ops.linear(x.view(1, M, K), w, N, b, epi, resid=resid, w_scale=wsc)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:
