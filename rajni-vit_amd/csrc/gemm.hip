@@ -330,7 +330,7 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 // shared tail of every bf16 tiling: bias/gamma for this lane's columns, then one row per m-tile
 template <int EPI, bool SF32, int MI, bool W8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n0w,
-                                              int l15, int g, const ResidPrefetch<MI>& pre) {
+                                              int l15, int g, ResidPrefetch<MI>& pre, int m_lo = 0) {
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
   float bias[16], gam[16];
@@ -340,14 +340,26 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
     bias[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
     gam[j] = (EPI == EPI_RESID && p.gamma != nullptr && n < p.N) ? p.gamma[n] : 1.f;
   }
-  if constexpr (W8) {   // dequantise: accumulator column n times the scale of W row n
+  float wsc[W8 ? 16 : 1];
+  if constexpr (W8) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = out_col<MAP>(n0w, g, j);
-      const float sc = n < p.N ? p.wscale[n] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[j >> 2][mi][j & 3] *= sc;
+      wsc[j] = n < p.N ? p.wscale[n] : 0.f;
     }
+  }
+  // Every vector-memory LOAD issued so far (these, and the residual rows prefetched in the last K step) has
+  // landed after this explicit wait, on EVERY path - including the ones that skip all uses (a row tile
+  // past M).  Without it hipcc's waitcnt pass carries "register X may still be the target of a load" back
+  // into the persistent K loop, and the first reuse of X there gets an s_waitcnt vmcnt(0) that drains the
+  // DMA queue in every K step (measured: -15 % on the 3-stage tiling).  It costs nothing here: the uses
+  // below need the same wait, and vector-memory ops retire in order.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  if constexpr (W8) {   // dequantise: accumulator column n times the scale of W row n
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[j >> 2][mi][j & 3] *= wsc[j];
   }
   if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
     if (pre.valid) {   // interior tile whose residual rows were prefetched during the last K step
@@ -369,7 +381,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m_base + mi * 16 + l15;
-    if (m >= p.M) continue;
+    if (m >= p.M || m < m_lo) continue;
     float v[16];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -478,13 +490,8 @@ __device__ __forceinline__ void sched_half() {
   }
 }
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
-  static_assert(N == 0 || N == 1 || N == 5 || N == 6 || N == 7 || N == 8, "unsupported vmcnt");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  else if (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-  else if (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-  else if (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-  else if (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
 }
 
 template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false>
@@ -499,17 +506,36 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 
   // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
   //      (fp8 W: a piece = 16 rows x 64 B, lane -> row lane>>2, 16-byte unit lane&3)
-  const int r_in = lane >> 3, pch = lane & 7;
-  XSource<ALOAD> xs[4];
+  // NOTE on addressing: the DMA takes a 64-bit per-lane pointer (global_load_lds ... off); scalar base +
+  // 32-bit lane offset and buffer_load ... lds were built and measured, neither is faster.
+  // Register diet (the RESID instantiations are register bound, and a spilled lane constant is reloaded
+  // behind an s_waitcnt vmcnt(0) that drains the DMA queue):
+  //   * a ragged last row tile starts at M - 256 instead of clamping its rows (the rows it shares with the
+  //     previous tile are recomputed and masked in the epilogue), so every tile's rows are evenly spaced:
+  //     X needs TWO pointers per lane (pieces 0/2 and 1/3 differ by 16 rows = a scalar), and
+  //   * going to the next tile is `pointer += scalar delta` - no second pointer set, nothing for the
+  //     compiler to hoist (it used to precompute the next tile's 6 pointers at the start of every tile).
+  auto tile_m0 = [&](int tm_) { return tm_ * BM + BM > p.M ? p.M - BM : tm_ * BM; };   // host: M >= 256
+  XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : 4];   // fused im2col loader: one source per piece
+  const char* xp[2];                                 // plain loader: pieces 0/2 and 1/3
   const char* ws[C::PW];
   auto point_at = [&](int tile) {   // DMA source pointers of a tile
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int r_in = lane >> 3, pch = lane & 7;
+    if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 8 + r_in;
-      int m = tm * BM + row;
-      if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
-      xs[i].init(p, m, pch ^ key_x(row));
+      for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 4 + i) * 8 + r_in;     // key_x(row + 16) == key_x(row)
+        xp[i] = reinterpret_cast<const char*>(p.X) + ((long)(tile_m0(tm) + row) * p.lda + (pch ^ key_x(row)) * 8) * 2;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + r_in;
+        int m = tm * BM + row;
+        if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
+        xs[i].init(p, m, pch ^ key_x(row));
+      }
     }
 #pragma unroll
     for (int i = 0; i < C::PW; ++i) {
@@ -522,11 +548,29 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       }
     }
   };
+  auto advance = [&](int from, int to) {   // retarget the DMA from tile `from` to tile `to`
+    if constexpr (ALOAD == ALOAD_PLAIN) {
+      const int tm0 = from / p.tiles_n, tn0 = from - tm0 * p.tiles_n;
+      const int tm1 = to / p.tiles_n, tn1 = to - tm1 * p.tiles_n;
+      const long dx = (long)(tile_m0(tm1) - tile_m0(tm0)) * p.lda * 2;
+      const long dw = (long)(tn1 - tn0) * C::BN * p.ldw * C::WB;
+      xp[0] += dx; xp[1] += dx;
+#pragma unroll
+      for (int i = 0; i < C::PW; ++i) ws[i] += dw;
+    } else {
+      point_at(to);
+    }
+  };
   auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
-    if (q < 4)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
-    else
+    if (q < 4) {
+      if constexpr (ALOAD == ALOAD_PLAIN)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xp[q & 1] + ((long)(q >> 1) * 16 * p.lda + k0) * 2),
+                                         LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+      else
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+    } else {
       __builtin_amdgcn_global_load_lds(GLB_PTR(ws[q - 4] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + q - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+    }
   };
   auto stage = [&](int kt, int st) {
 #pragma unroll
@@ -587,6 +631,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   int tile = xcd_tile_of(v, p.total_tiles);
   bf16x8 xa[MI], xb[MI];
   WFrag wa[4], wb[4];
+
+  constexpr int WBASE = (NS - 2) * C::PIECES;
+  auto interior = [&](int t) {   // a tile whose 256 rows and BN columns all exist
+    const int tm_ = t / p.tiles_n, tn_ = t - tm_ * p.tiles_n;
+    return tm_ * BM + BM <= p.M && tn_ * C::BN + C::BN <= p.N;
+  };
+  ResidPrefetch<MI> pre;
   point_at(tile);
 #pragma unroll
   for (int j = 0; j < NS; ++j) stage(j, j);
@@ -604,10 +655,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * C::BN;
+    const int m0 = ALOAD == ALOAD_PLAIN ? tile_m0(tm) : tm * BM, n0 = tn * C::BN;
+    const int m_lo = tm * BM;            // rows below it belong to the previous tile (ragged last tile only)
+    const bool inter = interior(tile);
     const int vn = v + gridDim.x;
     const bool more = vn < p.total_tiles;
-    ResidPrefetch<MI> pre;
     pre.valid = false;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -617,13 +669,13 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     for (int kt = 0; kt < nk; ++kt) {
       // the DMA of step kt loads K-tile kt+NS; from kt = nk-NS on that is the NEXT tile's K-tile
       // 0.. (when there is no next tile the pointers stay put: harmless re-loads nobody reads)
-      if (kt == nk - NS && more) point_at(xcd_tile_of(vn, p.total_tiles));
+      if (kt == nk - NS && more) advance(tile, xcd_tile_of(vn, p.total_tiles));
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
-      if (kt == nk - 1) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
+      if (kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
       half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
-      wait_step<(NS - 2) * C::PIECES>();
+      wait_step<WBASE>();
       __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
       half(T{}, xb, wb, xa, wa, st1, 0, dkt, st);
@@ -635,7 +687,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -970,6 +1022,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
+  if ((mode == 4 || mode == 5) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
   if (mode == 4 && p.K < 192) mode = 1;   // the persistent streams need >= NS + 1 K steps
   if (mode == 5 && p.K < 256) mode = 1;
   if (mode == 0) {
@@ -998,6 +1051,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     using C = wide::Cfg<2, 3, W8>;
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
+
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {

@@ -113,6 +113,35 @@ def test_linear_resid_layerscale(gather, stream_f32, tiling):
     close(host(y).reshape(want.shape), want, rel=1e-5 if stream_f32 else 1e-2, what="linear+resid")
 
 
+@pytest.mark.parametrize("K", [576, 768, 2112, 3072])
+@pytest.mark.parametrize("gather", [False, True])
+def test_linear_resid_fp32_stream_many_tiles(gather, K, tiling):
+    """The proj / fc2 shapes of the forward: fp32 residual stream, K long enough for the 256x128 tiling's
+    deferred epilogue I/O (residual rows loaded during the K loop, outputs stored during the NEXT tile's
+    loop), several tiles per persistent workgroup, ragged last row tile, in-place (y = resid) when not
+    gathered - exactly how forward.hip calls it."""
+    rng = np.random.default_rng(K + gather)
+    B, Nsrc, Np, Cc = 150, 197, 173, 768
+    rows = Np if gather else Nsrc
+    x = torch.randn(B, rows, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(Cc, K, device=DEV) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cc, device=DEV).to(torch.bfloat16).float()
+    resid = torch.randn(B, Nsrc, Cc, device=DEV)
+    idx = torch.from_numpy(np.stack([np.sort(rng.choice(Nsrc, Np, replace=False)) for _ in range(B)]).astype(np.int32)).to(DEV)
+    lin = x.float().reshape(-1, K) @ w.float().T + b          # fp32 torch reference (TF32 off by default on ROCm)
+    if gather:
+        r = torch.gather(resid, 1, idx.long()[:, :, None].expand(-1, -1, Cc))
+        y = ops.linear(x, ops.pack_weight(w), Cc, b, nat.EPI_BIAS_RESID, resid=resid, r_idx=idx)
+    else:
+        r = resid.clone()
+        out = resid.reshape(-1, Cc)                           # in place, like fc2 in the forward
+        y = ops.linear(x, ops.pack_weight(w), Cc, b, nat.EPI_BIAS_RESID, resid=resid, out=out)
+    want = (r.reshape(-1, Cc).double() + lin.double()).cpu().numpy()
+    got = y.reshape(-1, Cc).double().cpu().numpy()
+    err = np.abs(got - want).max()
+    assert err <= 2e-4 * np.abs(want).max(), f"max err {err:.3g}"
+
+
 # ---------------------------------------------------------------------------------------------
 # LayerNorm, gather
 # ---------------------------------------------------------------------------------------------
