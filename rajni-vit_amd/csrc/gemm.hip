@@ -450,6 +450,9 @@ struct XSource {
 #ifndef RAJNI_GEMM_W_AUX
 #define RAJNI_GEMM_W_AUX 0   // ... of the W (weight) loads
 #endif
+#ifndef RAJNI_GEMM_RELAX_FIRST
+#define RAJNI_GEMM_RELAX_FIRST 1
+#endif
 namespace wide {
 constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
@@ -649,6 +652,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #pragma unroll
   for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
   int st = 0;  // LDS stage of the current K step
+  // Output stores of a tile are still in flight when the next tile's K loop starts.  gfx9 counts stores in
+  // vmcnt as well and retires vector-memory ops in order, so the first counted wait of a tile may leave
+  // exactly the epilogue's stores outstanding instead of waiting for them to reach L2: an interior tile's
+  // epilogue issues NSTORE stores per wave after the DMA of K step 1 (a lower bound is all that is needed).
+  constexpr int NSTORE = RAJNI_GEMM_RELAX_FIRST ? (nat_order(EPI, SF32) ? 4 * MI : 2 * MI) : 0;
+  bool prev_full = false;          // the previous tile of this workgroup was interior
 
   while (true) {
 #ifdef RAJNI_GEMM_STAMPS
@@ -675,7 +684,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       if (kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
       half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
-      wait_step<WBASE>();
+      if (NSTORE > 0 && kt == 0 && prev_full) wait_step<WBASE + NSTORE>();
+      else wait_step<WBASE>();
       __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
       half(T{}, xb, wb, xa, wa, st1, 0, dkt, st);
@@ -697,6 +707,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       }
     }
 #endif
+    prev_full = inter;
     if (!more) break;
     v = vn;
     tile = xcd_tile_of(v, p.total_tiles);
