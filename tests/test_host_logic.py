@@ -226,3 +226,11 @@ def test_fp8_row_quantiser_properties():
     assert torch.equal(ops.dequantize_fp8(packed, s2), deq)
     with pytest.raises(ValueError):
         ops.pack_weight_fp8(torch.zeros(4, 24), torch.bfloat16, "cpu")
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles (or finds up to date) the gfx950 library, imports the package and
+    resolves every exported symbol - must stay in step with the ABI version."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
