@@ -119,6 +119,9 @@ int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
 /* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 (4 waves), 4 = 256x256x64 persistent,
  * 5 = 256x128x64 3-stage persistent */
 void rajni_debug_force_gemm_tiling(int mode);
+/* test hook / tuning: W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the
+ * plain column-fastest order; -k = blocks of k column tiles regardless of size */
+void rajni_debug_set_gemm_nblock_bytes(int bytes);
 /* diagnostic builds (-DRAJNI_GEMM_STAMPS) only: device buffer receiving 4 x uint64 s_memtime stamps per
  * workgroup of the 256x256 GEMM (start, main loop start, main loop end, end); NULL disables */
 void rajni_debug_set_gemm_stamps(void* buf);

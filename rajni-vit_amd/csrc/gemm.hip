@@ -41,6 +41,7 @@ struct GemmParams {
   void* Y; long ldc;            // output (fp32 when SF32: RESID / PATCH write the residual stream)
   int M, N, K;
   int tiles_n, total_tiles;
+  int nblk;                     // persistent tilings: column tiles per N block of the tile order (tile_mn)
   // patch-embed A loader / epilogue
   int cin, S, log2ps, gw, npatch;
   const void* pos; int pos_off; // pos-embed rows, activation dtype
@@ -450,6 +451,9 @@ struct XSource {
 #ifndef RAJNI_GEMM_W_AUX
 #define RAJNI_GEMM_W_AUX 0   // ... of the W (weight) loads
 #endif
+#ifndef RAJNI_GEMM_NBLK_BYTES
+#define RAJNI_GEMM_NBLK_BYTES (1600 * 1024)
+#endif
 #ifndef RAJNI_GEMM_RELAX_FIRST
 #define RAJNI_GEMM_RELAX_FIRST 1
 #endif
@@ -519,11 +523,25 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   //   * going to the next tile is `pointer += scalar delta` - no second pointer set, nothing for the
   //     compiler to hoist (it used to precompute the next tile's 6 pointers at the start of every tile).
   auto tile_m0 = [&](int tm_) { return tm_ * BM + BM > p.M ? p.M - BM : tm_ * BM; };   // host: M >= 256
+  // Tile order.  An XCD works through a contiguous range of tile ids, its 32 CUs on 32 consecutive ones.
+  // With id = (row tile, column tile) column-fastest, those 32 tiles span ALL column tiles: every XCD
+  // streams the whole W once per round, and W (4.7 MB for FC1) does not stay in a 4 MB L2 next to the X
+  // panels - measured 387 MB fetched per FC1 launch for 63 MB of operands.  Instead the columns are cut
+  // into blocks of `nblk` column tiles and the ids run (block, row tile, column in block): an XCD stays in
+  // one block for many rounds (its W slice stays L2 resident), at the price of reading X once per block.
+  const int tiles_m = p.total_tiles / p.tiles_n;
+  auto tile_mn = [&](int t, int& tm_, int& tn_) {
+    if (p.nblk >= p.tiles_n) { tm_ = t / p.tiles_n; tn_ = t - tm_ * p.tiles_n; return; }
+    const int per = p.nblk * tiles_m, blk = t / per, r = t - blk * per;
+    const int left = p.tiles_n - blk * p.nblk, nb = left < p.nblk ? left : p.nblk;
+    tm_ = r / nb; tn_ = blk * p.nblk + (r - tm_ * nb);
+  };
   XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : 4];   // fused im2col loader: one source per piece
   const char* xp[2];                                 // plain loader: pieces 0/2 and 1/3
   const char* ws[C::PW];
   auto point_at = [&](int tile) {   // DMA source pointers of a tile
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_mn(tile, tm, tn);
     const int r_in = lane >> 3, pch = lane & 7;
     if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
@@ -553,8 +571,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   };
   auto advance = [&](int from, int to) {   // retarget the DMA from tile `from` to tile `to`
     if constexpr (ALOAD == ALOAD_PLAIN) {
-      const int tm0 = from / p.tiles_n, tn0 = from - tm0 * p.tiles_n;
-      const int tm1 = to / p.tiles_n, tn1 = to - tm1 * p.tiles_n;
+      int tm0, tn0, tm1, tn1;
+      tile_mn(from, tm0, tn0);
+      tile_mn(to, tm1, tn1);
       const long dx = (long)(tile_m0(tm1) - tile_m0(tm0)) * p.lda * 2;
       const long dw = (long)(tn1 - tn0) * C::BN * p.ldw * C::WB;
       xp[0] += dx; xp[1] += dx;
@@ -637,7 +656,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 
   constexpr int WBASE = (NS - 2) * C::PIECES;
   auto interior = [&](int t) {   // a tile whose 256 rows and BN columns all exist
-    const int tm_ = t / p.tiles_n, tn_ = t - tm_ * p.tiles_n;
+    int tm_, tn_;
+    tile_mn(t, tm_, tn_);
     return tm_ * BM + BM <= p.M && tn_ * C::BN + C::BN <= p.N;
   };
   ResidPrefetch<MI> pre;
@@ -663,7 +683,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #ifdef RAJNI_GEMM_STAMPS
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_mn(tile, tm, tn);
     const int m0 = ALOAD == ALOAD_PLAIN ? tile_m0(tm) : tm * BM, n0 = tn * C::BN;
     const int m_lo = tm * BM;            // rows below it belong to the previous tile (ragged last tile only)
     const bool inter = interior(tile);
@@ -1027,6 +1048,24 @@ inline double launch_cost(int tiles, int per_cu, double tile_time) {
   return ((tiles + slots - 1) / slots) * tile_time;
 }
 
+int g_nblk_bytes = RAJNI_GEMM_NBLK_BYTES;   // W bytes of one N block (0 = plain order, < 0 = forced block size: tuning)
+
+// column tiles per N block of the persistent tile order (see tile_mn).  Measured on the ViT-B shapes
+// (tools/nblk_bench.py): blocks of ~1.5 MiB of W help once every block spans at least two rounds of tiles
+// (QKV at 197 tokens 179 -> 161 us, FC1 254 -> 239 us); with fewer rounds W is not re-read often enough
+// to pay for reading X once per block, and K = 3072 (fc2) never pays.
+inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes) {
+  if (g_nblk_bytes < 0) return -g_nblk_bytes < tiles_n ? -g_nblk_bytes : tiles_n;
+  if (g_nblk_bytes == 0) return tiles_n;
+  const long per_tile = (long)bn * K * wbytes;
+  const int fit = (int)(g_nblk_bytes / per_tile);
+  if (fit < 1 || fit >= tiles_n) return tiles_n;
+  const int blocks = (tiles_n + fit - 1) / fit;
+  const int rounds = tiles_n * tiles_m / 256;
+  if (rounds < 2 * blocks) return tiles_n;
+  return (tiles_n + blocks - 1) / blocks;
+}
+
 template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.stamps = rajni_g_stamps;
@@ -1056,13 +1095,14 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, W8 ? 1 : 2);
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
-
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, W8 ? 1 : 2);
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {
@@ -1078,6 +1118,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
 }  // namespace
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
+extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per kernel launch from two rocprofv3 PMC passes (rocpd sqlite output):
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out_f -o f -- python bench.py --steps 5 --warmup 2 ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out_w -o w -- python bench.py --steps 5 --warmup 2 ...
+    python tools/pmc_traffic.py out_f/f_results.db out_w/w_results.db > profiles/rNN_hbm_traffic_pmc.json
+
+Counters are in KiB; FETCH_SIZE is doubled on gfx950 (it tallies 128-byte requests at 64 bytes:
+MI355X_MICROARCH.md, HBM / rocprofv3 section).  These are L2 <-> fabric bytes: Infinity Cache hits included."""
+import json
+import re
+import sqlite3
+import sys
+
+BENCH_CLASS = {  # GEMM template arguments <EPI, ...> -> bench.py kernel class
+    0: "gemm_bf16_tn<bias>", 1: "gemm_bf16_tn<bias,gelu>", 2: "gemm_bf16_tn<bias,ls,resid>", 3: "gemm_bf16_tn<patch>"}
+
+
+def per_kernel(db_path, counter):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                       "group by kernel_name", (counter,)).fetchall()
+    return {re.sub(r"\(anonymous namespace\)::", "", n): (c, v) for n, c, v in rows}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    by_kernel, by_class = {}, {}
+    for name, (n, kib) in fetch.items():
+        if name.startswith("void at::") or "rocclr" in name:
+            continue
+        wn, wkib = write.get(name, (n, 0.0))
+        f_mb, w_mb = 2.0 * kib * 1024 / n / 1e6, wkib * 1024 / wn / 1e6
+        by_kernel[name] = {"launches": n, "fetch_MB_corrected": round(f_mb, 1), "write_MB": round(w_mb, 1)}
+        m = re.search(r"gemm_bf16_tn_(?:stream|128x128)<(\d)", name)
+        if m:
+            c = by_class.setdefault(BENCH_CLASS[int(m.group(1))], {"launches": 0, "f": 0.0, "w": 0.0})
+            c["launches"] += n; c["f"] += f_mb * n; c["w"] += w_mb * n
+    out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "),
+           "by_bench_class": {k: {"launches": v["launches"], "fetch_MB_per_launch": round(v["f"] / v["launches"], 1),
+                                  "write_MB_per_launch": round(v["w"] / v["launches"], 1),
+                                  "hbm_bytes_per_launch": int((v["f"] + v["w"]) / v["launches"] * 1e6)}
+                              for k, v in by_class.items()},
+           "by_kernel": by_kernel}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
