@@ -185,13 +185,13 @@ def main():
         # command and committed under profiles/ - null when that file does not cover the kernel
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")) as f:
                 traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_e_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                    "traffic_source": "profiles/r01_h_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": rec["launches"],
                     "all_gemm": {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in prof.items()}}

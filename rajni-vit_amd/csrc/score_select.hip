@@ -29,6 +29,19 @@ struct ScoreArgs {          // T = activation dtype (bf16_t or float)
 
 __device__ __forceinline__ float rank_key(float s) { return (s != s) ? INFINITY : s; }
 
+// sum over an aligned group of `width` (4, 8 or 16) consecutive lanes, every lane gets the total; DPP adds in
+// a fixed tree (bitwise reproducible): xor 1, xor 2, mirror within 8, mirror within 16
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group_sum(float v, int width) {
+  v = dpp_add<0xB1>(v);                    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                    // quad_perm [2,3,0,1]
+  if (width >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if (width >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
 template <bool COMPUTE, typename T>
 __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -62,17 +75,39 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     __syncthreads();
 
     // ---- logits[h][n] = q_cls[h] . k[n,h] / sqrt(D)   (importance.py:19)
+    // Work item = one 16-byte chunk c of K row n (C/8 chunks per row, lane-contiguous -> coalesced); the LP
+    // chunks of a head sit in LP consecutive lanes and are summed with DPP adds (ds_bpermute shuffles and an
+    // integer division per item made this loop 34 of the kernel's 60 us).  U loads in flight per thread.
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
-    for (int pair = grp; pair < N * H; pair += ngrp) {
-      const int n = pair / H, h = pair - n * H;
-      float kf[8];
-      load8<T>(base + (long)n * 3 * C + C + h * D + sub * 8, kf);
-      const float* qh = qcls + h * D + sub * 8;
-      float dot = 0.f;
+    {
+      constexpr int U = 8;
+      const int CP = C >> 3;
+      const int dn = SS_THREADS / CP, dc = SS_THREADS - dn * CP;   // item index += SS_THREADS
+      int n = tid / CP, c = tid - n * CP;
+      while (n < N) {
+        float kf[U][8];
+        int nn[U], cc[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot = fmaf(kf[j], qh[j], dot);
-      for (int o = LP >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-      if (sub == 0) region[h * N + n] = dot * inv_sqrt_d;
+        for (int u = 0; u < U; ++u) {
+          nn[u] = n; cc[u] = c;
+          if (n < N) load8<T>(base + (long)n * 3 * C + C + c * 8, kf[u]);
+          n += dn; c += dc;
+          if (c >= CP) { c -= CP; ++n; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (nn[u] < N) {
+            const float4 q0 = *reinterpret_cast<const float4*>(qcls + cc[u] * 8);
+            const float4 q1 = *reinterpret_cast<const float4*>(qcls + cc[u] * 8 + 4);
+            float dot = kf[u][0] * q0.x;
+            dot = fmaf(kf[u][1], q0.y, dot); dot = fmaf(kf[u][2], q0.z, dot); dot = fmaf(kf[u][3], q0.w, dot);
+            dot = fmaf(kf[u][4], q1.x, dot); dot = fmaf(kf[u][5], q1.y, dot); dot = fmaf(kf[u][6], q1.z, dot);
+            dot = fmaf(kf[u][7], q1.w, dot);
+            dot = group_sum(dot, LP);
+            if ((cc[u] & (LP - 1)) == 0) region[(cc[u] / LP) * N + nn[u]] = dot * inv_sqrt_d;
+          }
+        }
+      }
     }
     __syncthreads();
 
@@ -100,11 +135,17 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     for (int n = grp; n < N; n += ngrp) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const T* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
-      for (int h = 0; h < H; ++h) {
-        float vf[8];
-        load8<T>(vp + h * D, vf);
+      for (int h0 = 0; h0 < H; h0 += 12) {     // 12 head rows in flight; summed in head order (fixed tree)
+        float vf[12][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += vf[j];
+        for (int u = 0; u < 12; ++u)
+          if (h0 + u < H) load8<T>(vp + (h0 + u) * D, vf[u]);
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+          if (h0 + u < H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
+          }
       }
       float* dst = region + n * D + sub * 8;
 #pragma unroll
@@ -135,7 +176,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
         const float dlt = src[j] - mp[j];
         ss = fmaf(dlt, dlt, ss);
       }
-      for (int o = LP >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      ss = group_sum(ss, LP);
       if (sub == 0) sc[n] = sqrtf(ss);
     }
     __syncthreads();
