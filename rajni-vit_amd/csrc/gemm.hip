@@ -331,9 +331,51 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 // shared tail of every bf16 tiling: bias/gamma for this lane's columns, then one row per m-tile
 template <int EPI, bool SF32, int MI, bool W8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n0w,
-                                              int l15, int g, ResidPrefetch<MI>& pre, int m_lo = 0) {
+                                              int l15, int g, ResidPrefetch<MI>& pre, int m_lo = 0,
+                                              bool interior = false) {
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
+  if constexpr (MAP == MAP_SEC && (EPI == EPI_BIAS || EPI == EPI_GELU)) {
+    // interior tile of a bf16-output launch (QKV, FC1 - the bulk of all tiles): no row or column guard, the
+    // lane's 2 x 8 columns of bias (and fp8 scale) as four 16-byte loads, two 16-byte stores per row.  The
+    // guarded general path below costs ~3x the instructions in exec-mask branches alone.
+    if (interior) {
+      const int ca = n0w + 8 * g, cb = ca + 32;
+      float bs[16], ws[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { bs[j] = 0.f; ws[j] = 1.f; }
+      if (p.bias != nullptr) {
+        load8<float>(p.bias + ca, bs);
+        load8<float>(p.bias + cb, bs + 8);
+      }
+      if constexpr (W8) {
+        load8<float>(p.wscale + ca, ws);
+        load8<float>(p.wscale + cb, ws + 8);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the note in the general path
+      bf16_t* Y = reinterpret_cast<bf16_t*>(p.Y);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {   // accumulator (ni, rg) = j>>2, j&3  ->  v[0..7] columns ca.., v[8..15] columns cb..
+          const int ni = j >> 2, rg = j & 3, o = (ni >> 1) * 8 + (ni & 1) * 4 + rg;
+          v[o] = W8 ? fmaf(acc[ni][mi][rg], ws[o], bs[o]) : acc[ni][mi][rg] + bs[o];
+        }
+        if (EPI == EPI_GELU) {
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            const f32x2 y = gelu_pk(f32x2{v[j], v[j + 1]});
+            v[j] = y[0]; v[j + 1] = y[1];
+          }
+        }
+        bf16_t* row = Y + (long)(m_base + mi * 16 + l15) * p.ldc;
+        *reinterpret_cast<uint4*>(row + ca) = pack8(v);
+        *reinterpret_cast<uint4*>(row + cb) = pack8(v + 8);
+      }
+      return;
+    }
+  }
   float bias[16], gam[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -718,7 +760,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1095,14 +1137,14 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
-    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, W8 ? 1 : 2);
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);   // fp8 W: same blocks as bf16 (measured)
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
-    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, W8 ? 1 : 2);
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2);
     const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {

@@ -1,0 +1,16 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo/rajni-vit_amd")
+import torch, rajni_amd
+from rajni_amd import timm_shaped as ts
+sched = {3: {"keep_ratio": 0.88, "update": True}, 4: {"keep_ratio": 0.88, "update": True}, 7: {"keep_ratio": 0.80, "update": True}, 8: {"keep_ratio": 0.72, "update": True}}
+cfg = ts.CONFIGS["vit_base_patch16_224"]
+m = rajni_amd.RAJNIViTWrapper(ts.create_model(cfg, seed=0).to(torch.bfloat16).cuda(), sched).eval()
+if len(sys.argv) > 1 and sys.argv[1] == "fp8": m.set_weight_format("fp8")
+x = torch.randn(256, 3, 224, 224, device="cuda").to(torch.bfloat16)
+for _ in range(5): m(x)
+ts_ = []
+for r in range(8):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): m(x)
+    torch.cuda.synchronize(); ts_.append((time.perf_counter() - t0) / 10 * 1e3)
+print(f"{os.environ.get('RAJNI_HIP_LIB','default')[-20:]:22s} min {min(ts_):.3f} ms  med {sorted(ts_)[4]:.3f} ms")

@@ -63,7 +63,7 @@ def main():
     bad = 0
     for k, drains, scratch, spills in sorted(rows):
         prod = dispatched(k)
-        ok = drains == 0 and scratch == 0 and (spills == 0 or not prod)
+        ok = (drains == 0 and scratch == 0 and spills == 0) or not prod
         bad += not ok
         print(f"stream<{','.join(map(str, k))}>  in-loop vmcnt(0): {drains}  in-loop scratch: {scratch}  "
               f"scratch bytes/lane: {spills}  {'dispatched' if prod else 'test hook only'}  {'ok' if ok else 'VIOLATION'}")
