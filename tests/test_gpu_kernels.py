@@ -142,6 +142,27 @@ def test_linear_resid_fp32_stream_many_tiles(gather, K, tiling):
     assert err <= 2e-4 * np.abs(want).max(), f"max err {err:.3g}"
 
 
+@pytest.mark.parametrize("nblk", [1, 2, 4, 5, 7])
+def test_linear_tile_order_blocks_do_not_change_results(nblk, tiling):
+    """The persistent tilings walk their tiles in N blocks (an XCD keeps its W slice in L2).  Any block size
+    must give bit-identical results to the plain order: same tiles, same K order, different schedule.
+    2816 columns = 11 (256-wide) or 22 (128-wide) column tiles, so the last block is ragged for every size."""
+    M, N, K = 2900, 2816, 256
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = ops.pack_weight((torch.randn(N, K, device=DEV) * 0.1).to(torch.bfloat16))
+    b = torch.randn(N, device=DEV)
+    nat.lib().rajni_debug_set_gemm_nblock_bytes(0)
+    try:
+        ref = ops.linear(x, w, N, b, nat.EPI_BIAS_GELU).clone()
+        nat.lib().rajni_debug_set_gemm_nblock_bytes(-nblk)
+        got = ops.linear(x, w, N, b, nat.EPI_BIAS_GELU)
+        assert torch.equal(got, ref)
+    finally:
+        nat.lib().rajni_debug_set_gemm_nblock_bytes(1600 * 1024)
+    want = orc.gelu(x.double().cpu().numpy() @ w[:N].double().cpu().numpy().T + b.double().cpu().numpy())
+    close(host(got), want, what="blocked tile order")
+
+
 # ---------------------------------------------------------------------------------------------
 # LayerNorm, gather
 # ---------------------------------------------------------------------------------------------
