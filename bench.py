@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--weight-format", default="model", choices=["model", "fp8"],
                     help='"fp8": block Linear weights as e4m3 + per-row scale (BASELINE configs[4]); the headline '
                          'metric is quoted on "model" (bf16 weights)')
+    ap.add_argument("--schedule", default=None,
+                    help="JSON text or file {block: {keep_ratio, update}} (default: the README 4-stage schedule); "
+                         'BASELINE configs[3] is --model vit_large_patch16_384 --batch 64 --schedule \'{"4":{"keep_ratio":0.7},'
+                         '"12":{"keep_ratio":0.5},"20":{"keep_ratio":0.3}}\'')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -136,6 +140,10 @@ def main():
 
     cfg = ts.CONFIGS[args.model]
     schedule = README_SCHEDULE
+    if args.schedule:
+        text = open(args.schedule).read() if os.path.exists(args.schedule) else args.schedule
+        schedule = {int(k): {"keep_ratio": float(v["keep_ratio"]), "update": bool(v.get("update", True))}
+                    for k, v in json.loads(text).items()}
     B = args.batch
     model = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev)
     wrapped = rajni_amd.RAJNIViTWrapper(model, schedule).eval()
@@ -200,8 +208,8 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"{args.model} bf16{' activations, fp8 e4m3 block weights' if args.weight_format == 'fp8' else ''}, "
-                                  f"batch {B}/GPU, README 4-stage schedule "
-                                  f"{{3:.88,4:.88,7:.80,8:.72}}, synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
+                                  f"batch {B}/GPU, {'README 4-stage schedule {3:.88,4:.88,7:.80,8:.72}' if not args.schedule else 'schedule ' + json.dumps({k: v['keep_ratio'] for k, v in schedule.items()})}, "
+                                  f"synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
                       "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}"},
            "model_tflops": round(value * fl_img / 1e12, 1),
