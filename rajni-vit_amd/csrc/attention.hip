@@ -283,6 +283,11 @@ __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv
 #endif
   const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
   const int q = qbase + l31;
+  // Everything this wave has in flight (the next item's K/V DMA, its Q and index loads) was issued before
+  // this tile's math and has landed by now: wait for it HERE, before the output stores, so that the
+  // per-item barrier of the persistent kernel does not have to wait with vmcnt(0) - gfx9 counts stores in
+  // vmcnt too, and a wait after them exposes the whole write latency once per item.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   if (q < np) {
     bf16_t* op = a.out + ((long)b * np + q) * C + head * 64 + 4 * h;
 #pragma unroll
@@ -434,8 +439,14 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
   int nxt = item + gridDim.x;
   load_rows(nxt < n_items ? nxt : n_items - 1, srow_a, sq_a);
   int buf = 0;
+  // the builtin (not asm) on purpose: hipcc's waitcnt pass must know that nothing is pending at the loop
+  // header, or it waits with vmcnt(0) for the prefetched Q registers after the barrier - behind the stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): K/V, Q and indices of the first item
   while (true) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my LDS reads are done
+    // my DMA pieces landed (waited before the previous item's output stores; before the loop for the first
+    // item; just below for a wave without queries), my LDS reads are done
+    if (!active) __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // ... everyone's: buffer `buf` is complete
     asm volatile("" ::: "memory");
 #pragma unroll
