@@ -180,7 +180,7 @@ int rajni_vit_forward(const rajni_vit_plan* plan, const void* images, void* logi
 
 /* ---- measurement hooks (bench.py roofline): HIP-event timing per kernel class on the launch
  * stream.  mask bit i enables class i; classes listed by rajni_profile_class_name(). ---- */
-enum { RAJNI_NUM_KCLASS = 12 };
+enum { RAJNI_NUM_KCLASS = 13 };
 void rajni_profile_enable(unsigned mask);
 const char* rajni_profile_class_name(int kclass);
 /* synchronises the recorded events, ADDS them into the accumulators, returns them: per class the

@@ -25,7 +25,7 @@ const char* const kNames[RAJNI_NUM_KCLASS] = {
     "gemm_bf16_tn<bias>", "gemm_bf16_tn<bias,gelu>", "gemm_bf16_tn<bias,ls,resid>",
     "gemm_bf16_tn<patch>", "attn_bf16_d64", "layernorm_kernel", "score_select_kernel<fused>",
     "score_select_kernel<scores>", "score_select_kernel<select>", "gather_rows_kernel",
-    "cls_pos_kernel", "other"};
+    "cls_pos_kernel", "other", "gemm_bf16_tn<bias,ls,resid> K<=N"};
 }  // namespace
 
 unsigned long long* rajni_g_stamps = nullptr;

@@ -82,7 +82,8 @@ void rajni_set_error(const char* fmt, ...);
 enum KClass {
   KC_GEMM_BIAS = 0, KC_GEMM_GELU = 1, KC_GEMM_RESID = 2, KC_GEMM_PATCH = 3, KC_ATTENTION = 4,
   KC_LAYERNORM = 5, KC_SCORE_SELECT = 6, KC_IMPORTANCE = 7, KC_SELECT = 8, KC_GATHER = 9,
-  KC_CLS_POS = 10, KC_OTHER = 11
+  KC_CLS_POS = 10, KC_OTHER = 11,
+  KC_GEMM_RESID_SQ = 12   // residual GEMM with K <= N (the attention projection): bound by its fp32-stream epilogue
 };
 // event bracket around one launch when the class is enabled
 struct ProfScope {

@@ -1128,8 +1128,11 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     else mode = 1;
   }
   static bool attr[5] = {false, false, false, false, false};   // [2] small, [3] wide, [4] mid
+  // algorithmic bytes: X + W + output (+ the residual rows read), fp32 where the residual stream is fp32
+  constexpr double ysz = (SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH)) ? 4.0 : 2.0;
+  constexpr double rsz = EPI == EPI_RESID ? (SF32 ? 4.0 : 2.0) : 0.0;
   ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
-                 2.0 * ((double)p.M * p.K + (double)p.M * p.N) + (W8 ? 1.0 : 2.0) * (double)p.N * p.K);
+                 2.0 * (double)p.M * p.K + (ysz + rsz) * (double)p.M * p.N + (W8 ? 1.0 : 2.0) * (double)p.N * p.K);
   int rc;
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
@@ -1191,8 +1194,8 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
       case RAJNI_EPI_BIAS_RESID:
         RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0, RAJNI_ERR_INVALID,
                       "rajni_linear: RESID epilogue needs resid and ldr %% 8 == 0");
-        return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true, true>(p, KC_GEMM_RESID, s)
-                            : launch_gemm<EPI_RESID, ALOAD_PLAIN, false, true>(p, KC_GEMM_RESID, s);
+        return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true, true>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s)
+                            : launch_gemm<EPI_RESID, ALOAD_PLAIN, false, true>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s);
       default:
         rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
         return RAJNI_ERR_INVALID;
@@ -1204,7 +1207,7 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
       case RAJNI_EPI_BIAS_GELU: return f32::launch<EPI_GELU, ALOAD_PLAIN>(p, KC_GEMM_GELU, s);
       case RAJNI_EPI_BIAS_RESID:
         RAJNI_REQUIRE(a.resid != nullptr, RAJNI_ERR_INVALID, "rajni_linear: RESID epilogue needs resid");
-        return f32::launch<EPI_RESID, ALOAD_PLAIN>(p, KC_GEMM_RESID, s);
+        return f32::launch<EPI_RESID, ALOAD_PLAIN>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s);
       default:
         rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
         return RAJNI_ERR_INVALID;
@@ -1216,8 +1219,8 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
     case RAJNI_EPI_BIAS_RESID:
       RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0, RAJNI_ERR_INVALID,
                     "rajni_linear: RESID epilogue needs resid and ldr %% 8 == 0");
-      return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true>(p, KC_GEMM_RESID, s)
-                          : launch_gemm<EPI_RESID, ALOAD_PLAIN, false>(p, KC_GEMM_RESID, s);
+      return a.stream_f32 ? launch_gemm<EPI_RESID, ALOAD_PLAIN, true>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s)
+                          : launch_gemm<EPI_RESID, ALOAD_PLAIN, false>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s);
     default:
       rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
       return RAJNI_ERR_INVALID;

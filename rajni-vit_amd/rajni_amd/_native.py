@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RAJNI_HIP_LIB") or os.path.join(_HERE, "lib", "libraj
 
 RAJNI_F32, RAJNI_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2
-NUM_KCLASS = 12
+NUM_KCLASS = 13
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 

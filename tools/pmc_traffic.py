@@ -14,13 +14,25 @@ import sys
 
 BENCH_CLASS = {  # GEMM template arguments <EPI, ...> -> bench.py kernel class
     0: "gemm_bf16_tn<bias>", 1: "gemm_bf16_tn<bias,gelu>", 2: "gemm_bf16_tn<bias,ls,resid>", 3: "gemm_bf16_tn<patch>"}
+RESID_SQ = "gemm_bf16_tn<bias,ls,resid> K<=N"   # the projection: same kernel as fc2, every other residual launch
 
 
 def per_kernel(db_path, counter):
+    """{kernel name: (launches, sum KiB)}; the residual GEMM kernel is split by launch order into
+    '<name> [proj]' (even launches: a block runs proj, then fc2) and '<name> [fc2]'."""
     cur = sqlite3.connect(db_path).cursor()
-    rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
-                       "group by kernel_name", (counter,)).fetchall()
-    return {re.sub(r"\(anonymous namespace\)::", "", n): (c, v) for n, c, v in rows}
+    rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ? order by dispatch_id",
+                       (counter,)).fetchall()
+    out, seen = {}, {}
+    for name, v in rows:
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        if re.search(r"gemm_bf16_tn_(?:stream|128x128)<2,", name):
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            name += " [proj]" if k % 2 == 0 else " [fc2]"
+        c, t = out.get(name, (0, 0.0))
+        out[name] = (c + 1, t + v)
+    return out
 
 
 def main():
@@ -35,7 +47,8 @@ def main():
         by_kernel[name] = {"launches": n, "fetch_MB_corrected": round(f_mb, 1), "write_MB": round(w_mb, 1)}
         m = re.search(r"gemm_bf16_tn_(?:stream|128x128)<(\d)", name)
         if m:
-            c = by_class.setdefault(BENCH_CLASS[int(m.group(1))], {"launches": 0, "f": 0.0, "w": 0.0})
+            cls = RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
+            c = by_class.setdefault(cls, {"launches": 0, "f": 0.0, "w": 0.0})
             c["launches"] += n; c["f"] += f_mb * n; c["w"] += w_mb * n
     out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "),
            "by_bench_class": {k: {"launches": v["launches"], "fetch_MB_per_launch": round(v["f"] / v["launches"], 1),
