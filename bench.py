@@ -193,7 +193,7 @@ def main():
         # command and committed under profiles/ - null when that file does not cover the kernel
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_pmc.json")) as f:
                 traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -207,7 +207,7 @@ def main():
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic,
-                    "traffic_source": "profiles/r01_h_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                    "traffic_source": "profiles/r01_k_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": rec["launches"],
                     "all_gemm": {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
