@@ -199,12 +199,22 @@ __global__ void __launch_bounds__(AT_THREADS) attn_bf16_d64(const AttnArgs a) {
 // 32-key block).  NSUB = ceil(Np/32) is a template parameter so S stays in registers.
 // ---------------------------------------------------------------------------------------------
 constexpr int ATF_THREADS = 512;
+#ifndef RAJNI_ATTN_STAGE_MASK
+#define RAJNI_ATTN_STAGE_MASK 0x78   // bit NSUB-1: stage the output tile through LDS (measured: helps NSUB 4..7, not 1..3; 8 has no LDS left)
+#endif
+constexpr bool stage_o(int nsub) { return (RAJNI_ATTN_STAGE_MASK >> (nsub - 1)) & 1; }
 
 // exact-softmax attention of ONE 32-query tile against all NSUB*32 staged keys (shared by the
 // one-shot and the persistent kernels).  sk/sv: swizzled K / V images in LDS; qf: Q fragments.
+// so != NULL: a 4 KiB per-wave LDS staging area; the 32 x 64 output tile is written there and leaves as
+// whole 128-byte rows (four 16-byte stores per lane-row group).  Stored straight from the accumulator
+// layout a lane owns 8 bytes of 8 different rows per instruction: 32 partial cache lines each, which backed
+// up the vector-memory queue - the NEXT item's prefetch then stalled at issue (tools/attn_stamps.py:
+// prefetch issue 2.5k + stores 1.7k of 11k cycles per item).
 template <int NSUB>
 __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv, const bf16x8 (&qf)[4],
-                                                  const AttnArgs& a, int b, int head, int qbase, int lane) {
+                                                  const AttnArgs& a, int b, int head, int qbase, int lane,
+                                                  char* so = nullptr) {
   const int l31 = lane & 31, h = lane >> 5, g = lane >> 4, l15 = lane & 15;
   const int np = a.np, C = a.H * 64;
   // ---- S^T = K Q^T for every 32-key block
@@ -288,6 +298,31 @@ __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv
   // per-item barrier of the persistent kernel does not have to wait with vmcnt(0) - gfx9 counts stores in
   // vmcnt too, and a wait after them exposes the whole write latency once per item.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  if (so != nullptr) {
+    // staging image: row r = query, sixteen 8-byte units per row, 16-byte unit u at ((u ^ key(r)) << 4)
+    const int key = (l31 ^ (l31 >> 3)) & 7;
+    char* wr = so + l31 * 128 + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint2 w0, w1;
+      w0.x = pack2bf(o0[4 * t] * inv, o0[4 * t + 1] * inv);
+      w0.y = pack2bf(o0[4 * t + 2] * inv, o0[4 * t + 3] * inv);
+      w1.x = pack2bf(o1[4 * t] * inv, o1[4 * t + 1] * inv);
+      w1.y = pack2bf(o1[4 * t + 2] * inv, o1[4 * t + 3] * inv);
+      *reinterpret_cast<uint2*>(wr + ((t ^ key) << 4)) = w0;          // d = 8t + 4h .. +3
+      *reinterpret_cast<uint2*>(wr + (((4 + t) ^ key) << 4)) = w1;    // d = 32 + 8t + 4h .. +3
+    }
+    // same wave wrote and reads: only the LDS counter orders them
+    const int u = lane & 7;
+    bf16_t* ob = a.out + ((long)b * np + qbase) * C + head * 64 + u * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (lane >> 3) + 8 * j;
+      const uint4 v = *reinterpret_cast<const uint4*>(so + r * 128 + ((u ^ ((r ^ (r >> 3)) & 7)) << 4));
+      if (qbase + r < np) *reinterpret_cast<uint4*>(ob + (long)r * C) = v;
+    }
+    return;
+  }
   if (q < np) {
     bf16_t* op = a.out + ((long)b * np + q) * C + head * 64 + 4 * h;
 #pragma unroll
@@ -376,6 +411,7 @@ template <int NSUB>
 __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NSUB * 32, BUF = ROWS * 256, NP8 = ROWS / 8;   // pieces (8 rows) per operand
+  constexpr bool STAGE_O = stage_o(NSUB);
   constexpr int PER_WAVE = (NP8 + 7) / 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,7 +483,13 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
     // item; just below for a wave without queries), my LDS reads are done
     if (!active) __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef RAJNI_ATTN_STAMPS
+    const unsigned long long ts_arrive = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();                                  // ... everyone's: buffer `buf` is complete
+#ifdef RAJNI_ATTN_STAMPS
+    const unsigned long long ts_bar = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 4; ++s) { asm volatile("" : "+v"(qn[s])); qf[s] = qn[s]; }
@@ -465,10 +507,20 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
     load_q(nx, sq_a, qn);                      // Q of item i+1
     load_rows(nn, srow_a, sq_a);               // keep_idx entries of item i+2
     dma_item(nx, srow_use, buf ^ 1);           // K/V of item i+1 -> the other buffer
+#ifdef RAJNI_ATTN_STAMPS
+    const unsigned long long ts_issue = __builtin_amdgcn_s_memtime();
+#endif
     if (active) {
       const int b = item / a.H, head = item - b * a.H;
-      attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane);
+      attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane,
+                              STAGE_O ? smem + 2 * BUF + (qbase >> 5) * 4096 : nullptr);
     }
+#ifdef RAJNI_ATTN_STAMPS
+    if (a.stamps != nullptr && qbase == 0 && lane == 0) {   // wave 0: [0] barrier arrival, [3] released, [4] prefetch issued, [5] tile done
+      unsigned long long* o = a.stamps + (size_t)item * 8;
+      o[0] = ts_arrive; o[3] = ts_bar; o[4] = ts_issue; o[5] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     if (nxt >= n_items) break;
     item = nxt;
     nxt += gridDim.x;
@@ -569,7 +621,7 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
     hipLaunchKernelGGL(attn_bf16_d64_full<NSUB>, dim3(a.H, B), dim3(ATF_THREADS), lds, s, a);
     return RAJNI_OK;
   }
-  constexpr int lds = NSUB * 32 * 256 * 2;   // two K+V buffers
+  constexpr int lds = NSUB * 32 * 256 * 2 + (stage_o(NSUB) ? 8 * 4096 : 0);   // two K+V buffers (+ output staging)
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB>),

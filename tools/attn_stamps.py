@@ -16,7 +16,10 @@ for N in (197, 152, 87):
     torch.cuda.synchronize()
     nat.lib().rajni_debug_set_gemm_stamps(None)
     t = st.cpu().numpy().reshape(-1, 8).astype(np.float64)
-    t = t[(t[:, 1] > 0) & (t[:, 2] > 0)]
-    # the kernel records two s_memtime values per (image, head): after the S^T MFMAs and after the P.V MFMAs
-    print(f"N={N}: items with stamps {len(t)} | median cycles softmax + P.V phase (S^T done -> O done): "
-          f"{np.median(t[:, 2] - t[:, 1]):.0f}")
+    t = t[(t[:, 1] > 0) & (t[:, 2] > 0) & (t[:, 0] > 0)]
+    # wave 0 of the persistent kernel, per (image, head): [0] arrives at the per-item barrier, [3] released,
+    # [4] prefetch (Q, indices, K/V DMA of the next item) issued, [1] S^T MFMAs done, [2] softmax + P.V done, [5] stores issued
+    med = lambda x: float(np.median(x))
+    print(f"N={N}: {len(t)} items | median cycles: barrier wait {med(t[:,3]-t[:,0]):.0f} | prefetch issue {med(t[:,4]-t[:,3]):.0f} | "
+          f"S^T {med(t[:,1]-t[:,4]):.0f} | softmax+PV {med(t[:,2]-t[:,1]):.0f} | scale+stores {med(t[:,5]-t[:,2]):.0f} | "
+          f"item total (release -> done) {med(t[:,5]-t[:,3]):.0f}")
