@@ -119,8 +119,8 @@ __device__ __forceinline__ void store1(void* base, long off, float v) {
 
 // One output row m, columns nb..nb+15 (v = accumulators + bias on entry).
 // SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32.
-// v[0..7] are columns nbA..nbA+7 and v[8..15] columns nbB..nbB+7 of output row m (nbB = nbA + 8 for
-// the 16-consecutive mapping of the pipe tilings, nbA + 32 for the sector mapping below).
+// v[0..7] are columns nbA..nbA+7 and v[8..15] columns nbB..nbB+7 of output row m (nbB = nbA + 32: the
+// sector mapping MAP_SEC below).
 template <int EPI, bool SF32>
 __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nbA, int nbB, float* v, const float* gam) {
   long orow = m;
@@ -199,30 +199,24 @@ constexpr bool nat_order(int epi, bool sf32) { return sf32 && (epi == EPI_RESID 
 //            and the 4 lanes of a row write one whole 64-byte sector per 16-byte store instruction.
 //            (With 16 consecutive columns per lane every store instruction wrote 4 quarter sectors
 //            per row: the wide tiling's epilogue took 9.5k cycles per 256x256 tile, store-issue bound.)
-enum { MAP_P16 = 0, MAP_NAT = 1, MAP_SEC = 2 };
+enum { MAP_NAT = 1, MAP_SEC = 2 };
 constexpr int col_map(int epi, bool sf32) { return nat_order(epi, sf32) ? MAP_NAT : MAP_SEC; }
 
 template <int MAP>
 __device__ __forceinline__ int out_col(int n0w, int g, int j) {
   const int ni = j >> 2, rg = j & 3;
-  return MAP == MAP_NAT ? n0w + 16 * ni + 4 * g + rg
-       : MAP == MAP_SEC ? n0w + 32 * (ni >> 1) + 8 * g + 4 * (ni & 1) + rg
-                        : n0w + 16 * g + j;
+  return MAP == MAP_NAT ? n0w + 16 * ni + 4 * g + rg : n0w + 32 * (ni >> 1) + 8 * g + 4 * (ni & 1) + rg;
 }
 // W tile row (relative to the wave's first W row) read by fragment row l15 of n-tile ni
 template <int MAP>
 __device__ __forceinline__ int w_frag_row(int l15, int ni) {
-  return MAP == MAP_NAT ? ni * 16 + l15
-       : MAP == MAP_SEC ? 32 * (ni >> 1) + 8 * (l15 >> 2) + 4 * (ni & 1) + (l15 & 3)
-                        : 16 * (l15 >> 2) + ni * 4 + (l15 & 3);
+  return MAP == MAP_NAT ? ni * 16 + l15 : 32 * (ni >> 1) + 8 * (l15 >> 2) + 4 * (ni & 1) + (l15 & 3);
 }
 // swizzle key of a W tile row for 128-byte-row tilings: the 16 rows one ds_read_b128 lane group
 // touches must land in 16 distinct 16-byte slots of the 256-byte bank row
 template <int MAP>
 __device__ __forceinline__ int w_key(int row) {
-  return MAP == MAP_NAT ? (row >> 1) & 7
-       : MAP == MAP_SEC ? ((row >> 3) & 3) * 2 + ((row >> 1) & 1)
-                        : ((row >> 4) & 3) * 2 + ((row >> 1) & 1);
+  return MAP == MAP_NAT ? (row >> 1) & 7 : ((row >> 3) & 3) * 2 + ((row >> 1) & 1);
 }
 
 // ---- fp8 (e4m3) weights: 64-byte tile rows (BK = 64 one-byte elements) -----------------------------
@@ -503,7 +497,6 @@ namespace wide {
 constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
 
 template <int WN_, int NS_, bool W8_ = false> struct Cfg {
   static constexpr int BN = WN_ * 64;
@@ -1082,13 +1075,6 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
 #define RAJNI_W8_WIDE_NS_OR(w8) ((w8) ? RAJNI_W8_WIDE_NS : 2)
 int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
 int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stages), 4 wide 256x256x64, 5 mid 256x128x64 (tests)
-
-// rounds of workgroups a launch needs on 256 CUs at `per_cu` resident workgroups each, weighted by
-// the tile's relative duration: picks the tiling that finishes first
-inline double launch_cost(int tiles, int per_cu, double tile_time) {
-  const int slots = 256 * per_cu;
-  return ((tiles + slots - 1) / slots) * tile_time;
-}
 
 int g_nblk_bytes = RAJNI_GEMM_NBLK_BYTES;   // W bytes of one N block (0 = plain order, < 0 = forced block size: tuning)
 
