@@ -400,14 +400,17 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_full(const AttnA
 // which serialised K/V prefetch with compute (tools/attn_stamps.py: 9.8k of 16.4k cycles per item).  Its
 // completion is counted by hand: s_waitcnt vmcnt(0) before the per-item barrier.  M0 is saved/restored
 // inside the statement (M0 is compiler-reserved); recipe: cdna_hip_programming.md section 5.7.
-__device__ __forceinline__ void dma16(const bf16_t* src, char* dst) {
+// Scalar base + 32-bit lane byte offset: nothing but one v_add per piece on the vector side.
+__device__ __forceinline__ void dma16(const char* base, unsigned off, char* dst) {
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(dst));
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(lds), "s"(base) : "memory");
 }
 
-template <int NSUB>
+// G: rows are gathered through keep_idx (a.idx != NULL) - a template flag, so that the per-item prefetch
+// carries no pointer tests (they were 10 scalar branches per item).
+template <int NSUB, bool G>
 __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NSUB * 32, BUF = ROWS * 256, NP8 = ROWS / 8;   // pieces (8 rows) per operand
@@ -430,34 +433,44 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
   }
   const int tq = qbase + l31 < np ? qbase + l31 : np - 1;
 
-  auto load_rows = [&](int item, int (&srow)[PER_WAVE], int& sq) {   // keep_idx entries of an item
-    const int b = item / a.H;
-    const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+  // swizzled 16-byte chunk of this lane inside its K / V row.  Piece q = wave + 8 i covers rows 8 q + r_in:
+  // (row >> 1) & 7 = (4 (q & 1) + (r_in >> 1)) & 7 and q & 1 = wave & 1, so both are per-lane constants.
+  const unsigned ck = (unsigned)(pos ^ ((4 * (wave & 1) + (r_in >> 1)) & 7)) << 4;
+  const unsigned cv = (unsigned)(pos ^ (((r_in >> 1) & 1) << 2)) << 4;
+  const unsigned row_bytes = (unsigned)C3 * 2;
+
+  auto load_rows = [&](int b, int (&srow)[PER_WAVE], int& sq) {   // keep_idx entries of image b
+    if constexpr (G) {
+      const int* idx = a.idx + (long)b * np;
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) srow[i] = idx ? idx[trow[i]] : trow[i];
-    sq = idx ? idx[tq] : tq;
+      for (int i = 0; i < PER_WAVE; ++i) srow[i] = idx[trow[i]];
+      sq = idx[tq];
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER_WAVE; ++i) srow[i] = trow[i];
+      sq = tq;
+    }
   };
-  auto dma_item = [&](int item, const int (&srow)[PER_WAVE], int buf) {
-    const int b = item / a.H, head = item - b * a.H;
-    const bf16_t* img = a.qkv + (long)b * a.n_src * C3 + head * 64;
+  auto dma_item = [&](int b, int head, const int (&srow)[PER_WAVE], int buf) {
+    const char* bk = reinterpret_cast<const char*>(a.qkv) + ((size_t)b * a.n_src * C3 + head * 64 + C) * 2;
+    const char* bv = bk + (size_t)C * 2;
     char* sk = smem + buf * BUF;
     char* sv = sk + ROWS * 128;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int q = wave + 8 * i;            // piece index, wave uniform
       if (q < NP8) {
-        const int row = q * 8 + r_in;
-        const bf16_t* rp = img + (long)srow[i] * C3;
-        dma16(rp + C + ((pos ^ ((row >> 1) & 7)) << 3), sk + q * 1024);
-        dma16(rp + 2 * C + ((pos ^ (((row >> 1) & 1) << 2)) << 3), sv + q * 1024);
+        const unsigned ro = (unsigned)srow[i] * row_bytes;
+        dma16(bk, ro + ck, sk + q * 1024);
+        dma16(bv, ro + cv, sv + q * 1024);
       }
     }
   };
-  auto load_q = [&](int item, int sq, bf16x8 (&qf)[4]) {
-    const int b = item / a.H, head = item - b * a.H;
-    const bf16_t* qp = a.qkv + ((long)b * a.n_src + sq) * C3 + head * 64 + 8 * h;
+  auto load_q = [&](int b, int head, int sq, bf16x8 (&qf)[4]) {
+    const char* bq = reinterpret_cast<const char*>(a.qkv) + ((size_t)b * a.n_src * C3 + head * 64) * 2;
+    const unsigned qo = (unsigned)sq * row_bytes + 16 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(bq + (size_t)(qo + 32 * s));
   };
 
   int item = blockIdx.x;
@@ -469,11 +482,12 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
   // hipcc places its (then free) waits.
   int srow_a[PER_WAVE], sq_a;     // keep_idx entries of item i+1 (then i+2)
   bf16x8 qf[4], qn[4];
-  load_rows(item, srow_a, sq_a);
-  dma_item(item, srow_a, 0);
-  load_q(item, sq_a, qn);
+  int cb = item / a.H, chead = item - cb * a.H;   // (image, head) of the item being computed
+  load_rows(cb, srow_a, sq_a);
+  dma_item(cb, chead, srow_a, 0);
+  load_q(cb, chead, sq_a, qn);
   int nxt = item + gridDim.x;
-  load_rows(nxt < n_items ? nxt : n_items - 1, srow_a, sq_a);
+  load_rows((nxt < n_items ? nxt : n_items - 1) / a.H, srow_a, sq_a);
   int buf = 0;
   // the builtin (not asm) on purpose: hipcc's waitcnt pass must know that nothing is pending at the loop
   // header, or it waits with vmcnt(0) for the prefetched Q registers after the barrier - behind the stores
@@ -504,14 +518,15 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
     int srow_use[PER_WAVE];
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) srow_use[i] = srow_a[i];
-    load_q(nx, sq_a, qn);                      // Q of item i+1
-    load_rows(nn, srow_a, sq_a);               // keep_idx entries of item i+2
-    dma_item(nx, srow_use, buf ^ 1);           // K/V of item i+1 -> the other buffer
+    const int nb = nx / a.H, nhead = nx - nb * a.H;
+    load_q(nb, nhead, sq_a, qn);               // Q of item i+1
+    load_rows(nn / a.H, srow_a, sq_a);         // keep_idx entries of item i+2
+    dma_item(nb, nhead, srow_use, buf ^ 1);    // K/V of item i+1 -> the other buffer
 #ifdef RAJNI_ATTN_STAMPS
     const unsigned long long ts_issue = __builtin_amdgcn_s_memtime();
 #endif
     if (active) {
-      const int b = item / a.H, head = item - b * a.H;
+      const int b = cb, head = chead;
       attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane,
                               STAGE_O ? smem + 2 * BUF + (qbase >> 5) * 4096 : nullptr);
     }
@@ -523,6 +538,7 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
 #endif
     if (nxt >= n_items) break;
     item = nxt;
+    cb = nb; chead = nhead;                    // nx == nxt here
     nxt += gridDim.x;
     buf ^= 1;
   }
@@ -624,15 +640,20 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
   constexpr int lds = NSUB * 32 * 256 * 2 + (stage_o(NSUB) ? 8 * 4096 : 0);   // two K+V buffers (+ output staging)
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) { rajni_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e)); return RAJNI_ERR_LAUNCH; }
+    for (const void* fn : {reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, false>),
+                           reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, true>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) { rajni_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e)); return RAJNI_ERR_LAUNCH; }
+    }
     attr = true;
   }
   const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;   // 512-thread workgroups resident per CU
   const int items = a.H * B;
   const int grid = items < 256 * per_cu ? items : 256 * per_cu;
-  hipLaunchKernelGGL(attn_bf16_d64_stream<NSUB>, dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
+  if (a.idx != nullptr)
+    hipLaunchKernelGGL((attn_bf16_d64_stream<NSUB, true>), dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
+  else
+    hipLaunchKernelGGL((attn_bf16_d64_stream<NSUB, false>), dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
   return RAJNI_OK;
 }
 
