@@ -15,3 +15,10 @@ def test_linear_fuzz_against_torch():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(cases=250, seed=2026, verbose=False) == 0
+
+
+def test_attention_and_selection_fuzz_against_torch():
+    spec = importlib.util.spec_from_file_location("fuzz_attention", os.path.join(ROOT, "tools", "fuzz_attention.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(cases=80, seed=2026, verbose=False) == 0

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Randomised differential test of rajni_attention (packed-token softmax attention with the keep_idx gather
+fused into its loads) against a torch fp32 reference, and of rajni_score_select's selection against the
+defined rule applied to the device's own scores.  python tools/fuzz_attention.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rajni-vit_amd"))
+import numpy as np
+import torch
+from rajni_amd import ops, _native as nat
+
+
+def run(cases=100, seed=0, verbose=True):
+    rng = np.random.default_rng(seed)
+    dev, bad = "cuda", 0
+    for it in range(cases):
+        B = int(rng.integers(1, 40)); H = int(rng.choice([1, 2, 3, 6, 12, 16]))
+        N = int(rng.choice([rng.integers(2, 40), rng.integers(40, 260), rng.integers(260, 620)]))
+        Np = N if rng.random() < 0.3 else int(rng.integers(1, N + 1))
+        if B * N * H > 60000: B = max(1, 60000 // (N * H))
+        qkv = torch.randn(B, N, 3 * H * 64, device=dev).to(torch.bfloat16)
+        idx = None
+        if Np != N or rng.random() < 0.3:
+            idx = torch.stack([torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                          1 + torch.randperm(N - 1, device=dev)[: Np - 1].sort().values]) for _ in range(B)]).to(torch.int32)
+        nat.lib().rajni_debug_force_attention(int(rng.choice([0, 0, 1, 2])) if Np <= 256 else 0)
+        out = ops.attention(qkv, idx, H, 0.125).float()
+        q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        if idx is not None:
+            g = idx.long()[:, None, :, None].expand(-1, H, -1, 64)
+            q, k, v = q.gather(2, g), k.gather(2, g), v.gather(2, g)
+        ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+        ref = ref.permute(0, 2, 1, 3).reshape(B, Np, H * 64)
+        err = float((out - ref).abs().max()); scale = float(ref.abs().max()) + 1e-6
+        ok = err <= 2e-2 * scale and bool(torch.isfinite(out).all())
+        # selection on the same qkv: exactly the defined top-k of the device's scores, CLS first, ascending
+        keep = int(rng.integers(1, N)) if 1 < N <= 577 else 0      # score/select holds a token's V-bar in LDS: N <= 577
+        ok2 = True
+        if keep:
+            sc, kidx, nxt = ops.score_select(qkv, H, keep)
+            s = sc.float()
+            key = torch.where(torch.isnan(s), torch.full_like(s, float("inf")), s)[:, 1:]
+            order = torch.argsort(-key, dim=1, stable=True)[:, :keep]           # larger first, lower index first
+            want = torch.cat([torch.zeros(B, 1, dtype=torch.int64, device=dev), 1 + order.sort(dim=1).values], 1)
+            ok2 = bool(torch.equal(kidx.long(), want))
+        bad += not (ok and ok2)
+        if verbose and (not (ok and ok2) or it % 20 == 0):
+            print(f"[{it}] B={B} N={N} Np={Np} H={H} gather={idx is not None}: attn err {err:.3g}/{scale:.3g} "
+                  f"{'ok' if ok else 'FAIL'}; select keep={keep} {'ok' if ok2 else 'FAIL'}", flush=True)
+    nat.lib().rajni_debug_force_attention(0)
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    failures = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"{n} cases, {failures} failures")
+    sys.exit(1 if failures else 0)
