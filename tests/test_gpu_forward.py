@@ -271,3 +271,27 @@ def test_full_size_fp8_weights_same_invariants(full_size):
         assert torch.equal(sub, l8[5:9])
     finally:
         wrapped.set_weight_format("model")
+
+
+def test_large_384_aggressive_schedule_properties():
+    """BASELINE.json configs[3]: ViT-L/16 @384 (577 tokens, chunked attention, 24 blocks) with the aggressive
+    schedule {4: .7, 12: .5, 20: .3}: token counts, selection invariants, sub-batch bit-identity."""
+    cfg = ts.CONFIGS["vit_large_patch16_384"]
+    sched = {4: {"keep_ratio": 0.7}, 12: {"keep_ratio": 0.5}, 20: {"keep_ratio": 0.3}}
+    model = ts.create_model(cfg, seed=1).to(torch.bfloat16).to(DEV)
+    wrapped = rajni_amd.RAJNIViTWrapper(model, sched).eval().trace_scores(True)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    images = torch.randn(24, 3, 384, 384, generator=gen, device=DEV).to(torch.bfloat16)
+    logits = wrapped(images).float()
+    assert wrapped.get_last_stats()["token_counts"] == [577] * 5 + [404] * 8 + [202] * 8 + [61] * 3
+    assert torch.isfinite(logits).all()
+    trace = {i: {k: v.clone() for k, v in d.items()} for i, d in wrapped.get_last_trace().items()}
+    for i, d in trace.items():
+        idx = d["keep_idx"]
+        assert (idx[:, 0] == 0).all() and (idx[:, 1:] > idx[:, :-1]).all()
+        s = d["scores"].float().cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(idx.cpu().numpy(), orc.select_tokens(s, idx.shape[1] - 1))
+    sub = wrapped(images[7:12]).float()
+    assert torch.equal(sub, logits[7:12])
+    for i, d in wrapped.get_last_trace().items():
+        assert torch.equal(d["keep_idx"], trace[i]["keep_idx"][7:12])
