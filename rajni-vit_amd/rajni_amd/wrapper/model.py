@@ -185,7 +185,14 @@ class RAJNIViTWrapper(nn.Module):
         return desc
 
     def _all_params(self):
-        return [p for p in self.m.parameters()]
+        """The base model's parameters.  Walking the module tree costs ~150 us per call - exposed latency in the
+        sync -> forward -> sync metric of evaluate_model - so the list is cached and re-walked every 64th
+        forward (a Parameter OBJECT replaced in between is picked up then; in-place changes, `.to()` and
+        `load_state_dict` are seen immediately through data_ptr / _version)."""
+        self._param_calls = getattr(self, "_param_calls", 0) + 1
+        if getattr(self, "_param_list", None) is None or self._param_calls % 64 == 0:
+            self._param_list = [p for p in self.m.parameters()]
+        return self._param_list
 
     def _pack_weights(self, device, dtype):
         params = self._all_params()

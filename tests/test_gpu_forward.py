@@ -295,3 +295,28 @@ def test_large_384_aggressive_schedule_properties():
     assert torch.equal(sub, logits[7:12])
     for i, d in wrapped.get_last_trace().items():
         assert torch.equal(d["keep_idx"], trace[i]["keep_idx"][7:12])
+
+
+def test_weight_changes_are_picked_up():
+    """The wrapper packs the base model's weights once and caches them (and the parameter list): in-place
+    edits, load_state_dict and a replaced Parameter object must all invalidate the cache (Q4: the wrapper
+    shares parameters with the base model)."""
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]
+    model = ts.create_model(cfg, seed=3, std=0.08, bias_std=0.02, round_bf16=True)
+    w = rajni_amd.RAJNIViTWrapper(model, {1: {"keep_ratio": 0.7}}).to(DEV).to(torch.bfloat16).eval()
+    x = torch.randn(2, 3, 64, 64, device=DEV).to(torch.bfloat16)
+    y0 = w(x).float()
+    assert torch.equal(w(x).float(), y0)
+    with torch.no_grad():
+        model.head.bias.add_(1.0)                                  # in place: _version changes
+    y1 = w(x).float()
+    assert torch.allclose(y1, y0 + 1.0, atol=2e-2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["head.bias"] = sd["head.bias"] - 1.0
+    model.load_state_dict(sd)                                       # copy_ into the same storage
+    assert torch.allclose(w(x).float(), y0, atol=2e-2)
+    model.head.bias = torch.nn.Parameter(model.head.bias.detach() + 2.0)   # a NEW Parameter object
+    y2 = None
+    for _ in range(70):                                             # the parameter list is re-walked every 64th forward
+        y2 = w(x).float()
+    assert torch.allclose(y2, y0 + 2.0, atol=3e-2)
