@@ -132,19 +132,27 @@ __global__ void __launch_bounds__(AT_THREADS) attn_bf16_d64(const AttnArgs a) {
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * a.c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // Lazy rescale: the running reference m_run only moves when some query's block maximum exceeds it
+        // by more than 8 (in log2 units), so p = exp2(s c - m_run) <= 2^8 - exact in fp32, harmless in the
+        // bf16 P operand (same relative precision) - and the rescale of O (32 multiplies + an exp per key
+        // block) runs for the first block or two only.  One wave-uniform branch per block.
+        const float mxc = mx * a.c;
+        if (__builtin_amdgcn_ballot_w64(mxc > m_run + 8.0f) != 0) {
+          const float m_new = fmaxf(m_run, mxc);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first block: exp2(-inf) = 0
+          l_run *= alpha;
+          m_run = m_new;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
         float p[16];
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c, -m_new));
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c, -m_run));
           lsum += p[r];
         }
-        l_run = fmaf(l_run, alpha, lsum);
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        l_run += lsum;
         // ---- P^T (bf16) as the B operand: registers 8s .. 8s+7 feed k-step s; element j of half h
         //      is key 16s + 8(j>>2) + 4h + (j&3) - V^T below is read in that same key order
         bf16x8 pb[2];
