@@ -227,6 +227,20 @@ def main():
            "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
            "roofline": roofline}
 
+    if world == 1:
+        # opt-in shortcut, NOT part of `value`: the last block computed for the CLS row only (the head reads
+        # nothing else; same logits - tests/test_gpu_forward.py::test_cls_only_last_block_*).  `value` above is
+        # the row-for-row forward, the reference's op graph.
+        wrapped.set_last_block_cls_only(True)
+        for _ in range(3):
+            wrapped(images)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wrapped(images)
+        torch.cuda.synchronize(dev)
+        out["cls_only_last_block_images_per_sec"] = round(B * args.steps / (time.perf_counter() - t0), 1)
+        wrapped.set_last_block_cls_only(False)
     if world == 1 and not args.no_torch_baseline:
         # the "4x" denominator: unpruned timm-shaped base, stock PyTorch-ROCm ops, same batch
         base = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev).eval()

@@ -168,6 +168,12 @@ typedef struct {
   void* workspace; size_t workspace_bytes;     /* >= rajni_vit_workspace_bytes() */
   int32_t* token_counts;                       /* HOST int32[depth] out: tokens at block entry (model.py:43) */
   int logits_ld;                               /* row stride of `logits` in elements (0 = num_classes); % 8 == 0 */
+  int cls_only_last_block;                     /* 1: when the last block is not a pruning stage, compute it for the
+                                                  CLS row only - attention with the CLS query over all tokens,
+                                                  proj / MLP on B rows.  model.py:65-66 feeds only x[:, 0] to the
+                                                  head, so the logits are the same function; the other rows of the
+                                                  last block are never formed.  0 (default): every row, like the
+                                                  reference's op graph */
   int resid_bf16;                              /* 0 (default): the residual stream x is kept in fp32 between
                                                   blocks (2x closer to the fp32 reference than a bf16 stream, see
                                                   DESIGN.md); 1: keep it in bf16 like the reference's bf16 model */

@@ -667,6 +667,65 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// CLS-query attention: out[b, h*64 + d] = softmax_n(q[b,0,h] . k[b,n,h] * scale) . v[b,n,h,d] over all
+// N tokens - the only attention row the classifier head can see in the LAST block (model.py:65-66 reads
+// x[:, 0]).  One wave per (image, head): lanes over keys for the logits, lanes over d for the output.
+// fp32 math on the stored activations (P is not rounded to bf16 here).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) attn_cls_d64(const T* qkv, T* out, int N, int H, float c) {
+  extern __shared__ __attribute__((aligned(16))) float prob[];   // [N]
+  const int lane = threadIdx.x, head = blockIdx.x, b = blockIdx.y;
+  const int C = H * 64, C3 = 3 * C;
+  const T* img = qkv + (long)b * N * C3 + head * 64;
+  float q[64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) load8<T>(img + 8 * i, q + 8 * i);        // same address in every lane: broadcast
+  float mx = -INFINITY;
+  for (int n = lane; n < N; n += 64) {
+    const T* kr = img + (long)n * C3 + C;
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float kf[8];
+      load8<T>(kr + 8 * i, kf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot = fmaf(q[8 * i + j], kf[j], dot);
+    }
+    dot *= c;                                                             // log2 domain
+    prob[n] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    const float pr = __builtin_amdgcn_exp2f(prob[n] - mx);
+    prob[n] = pr;
+    sum += pr;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float acc = 0.f;                                                        // lane = d
+  const T* vc = img + 2 * C + lane;
+  for (int n = 0; n < N; ++n) acc = fmaf(prob[n], ld1(vc + (long)n * C3), acc);
+  st1(out + (long)b * C + head * 64 + lane, acc / sum);
+}
+
+int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,
+                         hipStream_t s) {
+  RAJNI_REQUIRE(qkv && out && D == 64 && B > 0 && H > 0 && N > 0 && B <= 65535, RAJNI_ERR_INVALID,
+                "attention_cls: bad arguments");
+  const float c = scale * 1.4426950408889634f;
+  ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)N * D, 2.0 * B * (double)N * H * D * (dtype == RAJNI_F32 ? 4.0 : 2.0));
+  if (dtype == RAJNI_F32)
+    hipLaunchKernelGGL(attn_cls_d64<float>, dim3(H, B), dim3(64), N * sizeof(float), s, (const float*)qkv, (float*)out, N, H, c);
+  else
+    hipLaunchKernelGGL(attn_cls_d64<bf16_t>, dim3(H, B), dim3(64), N * sizeof(float), s, (const bf16_t*)qkv, (bf16_t*)out, N, H, c);
+  RAJNI_CHECK_LAUNCH("attn_cls_d64");
+  return RAJNI_OK;
+}
+
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, int dtype, hipStream_t s) {
   RAJNI_REQUIRE(qkv && out, RAJNI_ERR_INVALID, "rajni_attention: null pointer");

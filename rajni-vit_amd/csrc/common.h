@@ -121,6 +121,8 @@ int launch_layernorm(const void* x, long xs, const float* w, const float* b, voi
                      int C, float eps, int x_f32, int dtype, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, int dtype, hipStream_t s);
+int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,
+                         hipStream_t s);
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
                         float eps, int keep, void* scores_out, int32_t* keep_idx,
                         void* next_scores, int dtype, hipStream_t s);

@@ -102,6 +102,38 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
 
+    if (p.cls_only_last_block && i == p.depth - 1 && blk.keep == 0 && N > 1) {
+      // ---- last block, not a pruning stage, caller opted in: only x[:, 0] reaches the head (model.py:65-66),
+      //      so attention runs for the CLS query alone (over all N keys) and proj / MLP on the B CLS rows
+      rc = launch_attention_cls(w.qkv, w.att, B, N, p.H, p.D, p.attn_scale, dt, s);
+      if (rc != RAJNI_OK) return rc;
+      g = rajni_linear_args{};
+      g.dtype = dt;
+      g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1; g.w_scale = blk.proj_s;
+      g.resid = cur; g.ldr = (long)N * C;            // residual row of image b = its CLS row
+      g.y = oth; g.ldc = C; g.M = B; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
+      rc = launch_linear(g, s);
+      if (rc != RAJNI_OK) return rc;
+      { char* t = cur; cur = oth; oth = t; }
+      N = 1;                                          // the stream is now [B, 1, C]
+      rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, B, C, p.ln_eps, sf32, dt, s);
+      if (rc != RAJNI_OK) return rc;
+      g = rajni_linear_args{};
+      g.dtype = dt;
+      g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b; g.w_scale = blk.fc1_s;
+      g.y = w.hid; g.ldc = p.hidden; g.M = B; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
+      rc = launch_linear(g, s);
+      if (rc != RAJNI_OK) return rc;
+      g = rajni_linear_args{};
+      g.dtype = dt;
+      g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2; g.w_scale = blk.fc2_s;
+      g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = B; g.N = C; g.K = p.hidden;
+      g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
+      rc = launch_linear(g, s);
+      if (rc != RAJNI_OK) return rc;
+      break;
+    }
+
     int Np = N;
     const int32_t* idx = nullptr;
     if (blk.keep > 0) {  // scheduled block (model.py:50)

@@ -55,7 +55,8 @@ class VitPlan(C.Structure):
                 ("pos_embed", c_void_p), ("blocks", C.POINTER(Block)),
                 ("norm_w", c_void_p), ("norm_b", c_void_p), ("head_w", c_void_p), ("head_b", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
-                ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int), ("resid_bf16", c_int)]
+                ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int), ("cls_only_last_block", c_int),
+                ("resid_bf16", c_int)]
 
 
 _SIGS = {

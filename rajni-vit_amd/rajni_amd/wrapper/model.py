@@ -74,6 +74,8 @@ class RAJNIViTWrapper(nn.Module):
         # storage format of the four big Linear weights of every block: "model" = the model dtype,
         # "fp8" = e4m3 bytes + per-row fp32 scale (`set_weight_format("fp8")`, bf16 models only)
         self._weight_format = "model"
+        # opt-in: compute the last block for the CLS row only (the head reads nothing else, model.py:65-66)
+        self._cls_only_last = False
 
     # ------------------------------------------------------------------------------------------
     def get_last_stats(self):
@@ -132,6 +134,16 @@ class RAJNIViTWrapper(nn.Module):
             for ours, theirs in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
                 out[f"blocks.{i}.{theirs}.weight"] = ops.dequantize_fp8(bw[ours + "_w"], bw[ours + "_s"])
         return out
+
+    def set_last_block_cls_only(self, on: bool = True):
+        """When the last block is not a pruning stage, run it for the CLS row only: CLS-query attention over all
+        tokens, proj / MLP on B rows.  The logits are the same function of the input (the reference's head reads
+        x[:, 0] only); the other rows of the last block are never formed.  Off by default: the default forward
+        executes the reference's op graph row for row."""
+        if bool(on) != self._cls_only_last:
+            self._cls_only_last = bool(on)
+            self._drop_plans()
+        return self
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
@@ -247,7 +259,8 @@ class RAJNIViTWrapper(nn.Module):
     def _build_plan(self, B: int, S: int, device, dtype):
         W = self._pack_weights(device, dtype)
         d = W["desc"]
-        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16)
+        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16,
+               self._cls_only_last)
         if self._plan is not None and self._plan[0] == key:
             return self._plan
         if key in self._plans:
@@ -309,6 +322,7 @@ class RAJNIViTWrapper(nn.Module):
         plan.token_counts = tc
         plan.logits_ld = (d["num_classes"] + 7) // 8 * 8
         plan.resid_bf16 = int(self._resid_bf16)
+        plan.cls_only_last_block = int(self._cls_only_last)
         nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes

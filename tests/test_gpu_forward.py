@@ -320,3 +320,45 @@ def test_weight_changes_are_picked_up():
     for _ in range(70):                                             # the parameter list is re-walked every 64th forward
         y2 = w(x).float()
     assert torch.allclose(y2, y0 + 2.0, atol=3e-2)
+
+
+@pytest.mark.parametrize("name,dtype,fp8", [("micro_fp32", torch.bfloat16, False), ("base224_fp32", torch.bfloat16, False),
+                                            ("deit3_fp32", torch.bfloat16, False), ("base224_fp32", torch.bfloat16, True),
+                                            ("tiny224_fp32", torch.float32, False)])
+def test_cls_only_last_block_gives_the_same_logits(name, dtype, fp8):
+    """`set_last_block_cls_only(True)`: the last block is computed for the CLS row only (the head reads nothing
+    else, model.py:65-66).  Same logits as the row-for-row forward up to summation order (the CLS attention
+    row is a VALU kernel with an un-rounded P; the B-row GEMMs take the 128x128 tiling), same stats, same
+    selections; and it stays within the parity bar against the reference fixture."""
+    meta, data = load_case(name)
+    cfg = ts.CONFIGS[meta["cfg_name"]]
+    model = ts.create_model(cfg, seed=meta["seed"], std=meta["std"], bias_std=meta["bias_std"], round_bf16=True)
+    wrapped = rajni_amd.RAJNIViTWrapper(model, meta["schedule"]).to(DEV).to(dtype).eval()
+    if fp8:
+        wrapped.set_weight_format("fp8")
+    images = torch.from_numpy(case_images(meta, data)).to(DEV)
+    forced = {i: torch.from_numpy(data[f"blk{i}.keep_idx"]).to(DEV) for i in pruned_blocks(meta)}
+    wrapped.force_keep_idx(forced)
+    full = wrapped(images).float().cpu().numpy()
+    stats = wrapped.get_last_stats()
+    wrapped.set_last_block_cls_only(True)
+    fast = wrapped(images).float().cpu().numpy()
+    assert wrapped.get_last_stats() == stats
+    scale = np.abs(full).max()
+    tol = 2e-5 if dtype == torch.float32 else 8e-3          # bf16 logits: one output ulp (2^-8 of the value) may flip
+    assert np.abs(fast - full).max() <= tol * scale, np.abs(fast - full).max() / scale
+    if not fp8:
+        ref = data["logits"]
+        assert np.abs(fast - ref).max() <= (1e-3 if dtype == torch.float32 else 1e-2) * np.abs(ref).max()
+    wrapped.set_last_block_cls_only(False)
+    assert np.array_equal(wrapped(images).float().cpu().numpy(), full)
+
+
+def test_cls_only_last_block_is_skipped_when_the_last_block_prunes():
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]
+    model = ts.create_model(cfg, seed=2, std=0.08, bias_std=0.02, round_bf16=True)
+    w = rajni_amd.RAJNIViTWrapper(model, {3: {"keep_ratio": 0.5}}).to(DEV).to(torch.bfloat16).eval()
+    x = torch.randn(3, 3, 64, 64, device=DEV).to(torch.bfloat16)
+    a = w(x).float()
+    b = w.set_last_block_cls_only(True)(x).float()
+    assert torch.equal(a, b) and w.get_last_trace()[3]["keep_idx"].shape[1] == orc.keep_count(0.5, 17) + 1
