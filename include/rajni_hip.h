@@ -122,6 +122,9 @@ void rajni_debug_force_gemm_tiling(int mode);
 /* test hook / tuning: W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the
  * plain column-fastest order; -k = blocks of k column tiles regardless of size */
 void rajni_debug_set_gemm_nblock_bytes(int bytes);
+/* tuning hook: 1 = launch the persistent GEMMs with the smallest grid that still finishes in the same number
+ * of tile rounds (a multiple of 8 workgroups), 0 = one workgroup per CU (default) */
+void rajni_debug_set_gemm_balanced_grid(int on);
 /* diagnostic builds (-DRAJNI_GEMM_STAMPS) only: device buffer receiving 4 x uint64 s_memtime stamps per
  * workgroup of the 256x256 GEMM (start, main loop start, main loop end, end); NULL disables */
 void rajni_debug_set_gemm_stamps(void* buf);

@@ -498,14 +498,17 @@ constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
 
-template <int WN_, int NS_, bool W8_ = false> struct Cfg {
+template <int WN_, int NS_, bool W8_ = false, int NW_ = 8> struct Cfg {   // WN_ = 64-column groups of the tile
   static constexpr int BN = WN_ * 64;
   static constexpr int WB = W8_ ? 1 : 2;         // bytes per W element
   static constexpr int W_BYTES = BN * BK * WB;
   static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
   static constexpr int LDS_BYTES = NS_ * STAGE_BYTES;
-  static constexpr int PW = W_BYTES / 8192;      // W pieces (1 KiB) per wave per K step
-  static constexpr int PIECES = 4 + PW;          // + 4 X pieces
+  static constexpr int XP = X_BYTES / 1024 / NW_;   // X pieces (1 KiB) per wave per K step: 4 with 8 waves
+  static constexpr int PW = W_BYTES / 1024 / NW_;   // W pieces per wave per K step
+  static constexpr int PIECES = XP + PW;
+  // W pieces 32 tile rows apart share their swizzle key (every map): one pointer per piece of the first 32 rows
+  static constexpr int NPW = PW < (W8_ ? 2 : 4) ? PW : (W8_ ? 2 : 4);
 };
 
 // first DMA piece issued after MFMA group g of a half step.  RAJNI_GEMM_DMA_FRONT pieces per group
@@ -519,16 +522,27 @@ __host__ __device__ constexpr int dma_first(int g, int pieces, int groups) {
                                   : g * pieces / groups;
 }
 // issue order of one half step: MI groups of {4 MFMAs, fragment reads, DMA pieces}
-template <int G, int MI, bool DMA, int PIECES>
+// fragment reads issued after MFMA group g of a half step: spread evenly (0), or RAJNI_GEMM_READ_FRONT per
+// group until they run out - the reads of a half step feed the NEXT one and the stage they come from is
+// released (lgkmcnt(0) + barrier) at its end, so reads issued in the last groups expose their latency there
+#ifndef RAJNI_GEMM_READ_FRONT
+#define RAJNI_GEMM_READ_FRONT 0
+#endif
+__host__ __device__ constexpr int rd_first(int g, int mi, int ni) {
+  return RAJNI_GEMM_READ_FRONT > 0 ? (g * RAJNI_GEMM_READ_FRONT < mi + ni ? g * RAJNI_GEMM_READ_FRONT : mi + ni)
+                                   : g + g * ni / mi;
+}
+template <int G, int MI, bool DMA, int PIECES, int NI = 4>
 __device__ __forceinline__ void sched_half() {
   if constexpr (G < MI) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((G + 1) * 4 / MI - G * 4 / MI), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+    if constexpr (rd_first(G + 1, MI, NI) - rd_first(G, MI, NI) > 0)
+      __builtin_amdgcn_sched_group_barrier(0x100, rd_first(G + 1, MI, NI) - rd_first(G, MI, NI), 0);
     if constexpr (DMA) {
       constexpr int nd = dma_first(G + 1, PIECES, MI) - dma_first(G, PIECES, MI);
       if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
     }
-    sched_half<G + 1, MI, DMA, PIECES>();
+    sched_half<G + 1, MI, DMA, PIECES, NI>();
   }
 }
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
@@ -536,12 +550,15 @@ template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) +
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
 }
 
-template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p) {
-  using C = Cfg<WN, NS, W8>;
+// NH = 64-column groups per wave: 1 = eight waves of (MI*16) x 64, 2 = FOUR waves of 128 x 128 (one per SIMD,
+// accumulators in the AGPR half of the register file; a third fewer LDS fragment bytes per MFMA)
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int NH = 1>
+__global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream(const GemmParams p) {
+  using C = Cfg<WN * NH, NS, W8, WM * WN>;
+  constexpr int NI = 4 * NH;                   // 16-column n-tiles per wave
   using WFrag = typename WFragT<W8>::type;   // a W fragment as it sits in LDS: 8 bf16, or 8 fp8 bytes
   constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
-  static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
+  static_assert((WM * WN == 8 || WM * WN == 4) && WM * MI * 16 == BM, "4 or 8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,9 +588,9 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     const int left = p.tiles_n - blk * p.nblk, nb = left < p.nblk ? left : p.nblk;
     tm_ = r / nb; tn_ = blk * p.nblk + (r - tm_ * nb);
   };
-  XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : 4];   // fused im2col loader: one source per piece
-  const char* xp[2];                                 // plain loader: pieces 0/2 and 1/3
-  const char* ws[C::PW];
+  XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : C::XP];   // fused im2col loader: one source per piece
+  const char* xp[2];                                 // plain loader: even and odd pieces (16 rows apart each)
+  const char* ws[C::NPW];
   auto point_at = [&](int tile) {   // DMA source pointers of a tile
     int tm, tn;
     tile_mn(tile, tm, tn);
@@ -581,20 +598,20 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 4 + i) * 8 + r_in;     // key_x(row + 16) == key_x(row)
+        const int row = (wave * C::XP + i) * 8 + r_in;     // key_x(row + 16) == key_x(row)
         xp[i] = reinterpret_cast<const char*>(p.X) + ((long)(tile_m0(tm) + row) * p.lda + (pch ^ key_x(row)) * 8) * 2;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + r_in;
+      for (int i = 0; i < C::XP; ++i) {
+        const int row = (wave * C::XP + i) * 8 + r_in;
         int m = tm * BM + row;
         if (m > p.M - 1) m = p.M - 1;  // clamp: duplicates are computed but never stored
         xs[i].init(p, m, pch ^ key_x(row));
       }
     }
 #pragma unroll
-    for (int i = 0; i < C::PW; ++i) {
+    for (int i = 0; i < C::NPW; ++i) {
       if constexpr (W8) {
         const int row = (wave * C::PW + i) * 16 + (lane >> 2);
         ws[i] = reinterpret_cast<const char*>(p.W) + (long)(tn * C::BN + row) * p.ldw + (((lane & 3) ^ w_key8<MAP>(row)) << 4);
@@ -613,20 +630,25 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       const long dw = (long)(tn1 - tn0) * C::BN * p.ldw * C::WB;
       xp[0] += dx; xp[1] += dx;
 #pragma unroll
-      for (int i = 0; i < C::PW; ++i) ws[i] += dw;
+      for (int i = 0; i < C::NPW; ++i) ws[i] += dw;
     } else {
       point_at(to);
     }
   };
   auto dma_piece = [&](int q, int k0, char* dx) {   // piece q of this wave: X 0..3 then W 0..PW-1
-    if (q < 4) {
+    if (q < C::XP) {
       if constexpr (ALOAD == ALOAD_PLAIN)
         __builtin_amdgcn_global_load_lds(GLB_PTR(xp[q & 1] + ((long)(q >> 1) * 16 * p.lda + k0) * 2),
-                                         LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+                                         LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
       else
-        __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * 4 + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
     } else {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ws[q - 4] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + q - 4) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+      const int i = q - C::XP;   // W piece i: pointer i % NPW, (i / NPW) * 32 tile rows further down
+      if constexpr (C::PW <= C::NPW)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+      else
+        __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i % C::NPW] + ((long)(i / C::NPW) * 32 * p.ldw + k0) * C::WB),
+                                         LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
     }
   };
   auto stage = [&](int kt, int st) {
@@ -639,9 +661,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
   const int xr0 = wm * (MI * 16) + l15;
-  const int wr0 = wn * 64 + w_frag_row<MAP>(l15, 0);
-  // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same)
-  auto w_ni_off = [](int ni) { return (w_frag_row<MAP>(0, ni) - w_frag_row<MAP>(0, 0)) * (64 * C::WB); };
+  const int wr0 = wn * (64 * NH) + w_frag_row<MAP>(l15, 0);
+  // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same);
+  // n-tiles 4.. are the wave's second 64-column group = 64 tile rows further down
+  auto w_ni_off = [](int ni) { return ((ni >> 2) * 64 + w_frag_row<MAP>(0, ni & 3) - w_frag_row<MAP>(0, 0)) * (64 * C::WB); };
   int xo[2], wo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -652,34 +675,34 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ w_key<MAP>(wr0)) << 4);
   }
 
-  f32x4 acc[4][MI];  // [ni][mi]
+  f32x4 acc[NH][4][MI];  // [column group][ni][mi]
 
   // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
   // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage dst
-  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], WFrag (&wc)[4], bf16x8 (&xn)[MI], WFrag (&wn_)[4],
+  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], WFrag (&wc)[NI], bf16x8 (&xn)[MI], WFrag (&wn_)[NI],
                   int rst, int rks, int dkt, int dst) {
     constexpr bool DMA = decltype(dma_c)::value;
     const char* sb = smem + rst * C::STAGE_BYTES;
     char* dx = smem + dst * C::STAGE_BYTES;
     const int k0 = dkt * BK;
-    bf16x8 wv[4];
+    bf16x8 wv[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) wv[ni] = w_frag_bf16(wc[ni]);
+    for (int ni = 0; ni < NI; ++ni) wv[ni] = w_frag_bf16(wc[ni]);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ni], xc[mi], acc[ni][mi], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)
+        acc[ni >> 2][ni & 3][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ni], xc[mi], acc[ni >> 2][ni & 3][mi], 0, 0, 0);
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
 #pragma unroll
-      for (int wi = mi * 4 / MI; wi < (mi + 1) * 4 / MI; ++wi)
+      for (int wi = mi * NI / MI; wi < (mi + 1) * NI / MI; ++wi)
         wn_[wi] = *reinterpret_cast<const WFrag*>(sb + wo[rks] + w_ni_off(wi));
       if constexpr (DMA) {
 #pragma unroll
         for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
       }
     }
-    sched_half<0, MI, DMA, C::PIECES>();
+    sched_half<0, MI, DMA, C::PIECES, NI>();
   };
   using T = std::true_type; using F = std::false_type;
 
@@ -687,7 +710,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   int v = blockIdx.x;
   int tile = xcd_tile_of(v, p.total_tiles);
   bf16x8 xa[MI], xb[MI];
-  WFrag wa[4], wb[4];
+  WFrag wa[NI], wb[NI];
 
   constexpr int WBASE = (NS - 2) * C::PIECES;
   auto interior = [&](int t) {   // a tile whose 256 rows and BN columns all exist
@@ -703,7 +726,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const WFrag*>(smem + wo[0] + w_ni_off(i));
+  for (int i = 0; i < NI; ++i) wa[i] = *reinterpret_cast<const WFrag*>(smem + wo[0] + w_ni_off(i));
 #pragma unroll
   for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + xo[0] + i * 2048);
   int st = 0;  // LDS stage of the current K step
@@ -711,7 +734,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
   // vmcnt as well and retires vector-memory ops in order, so the first counted wait of a tile may leave
   // exactly the epilogue's stores outstanding instead of waiting for them to reach L2: an interior tile's
   // epilogue issues NSTORE stores per wave after the DMA of K step 1 (a lower bound is all that is needed).
-  constexpr int NSTORE = RAJNI_GEMM_RELAX_FIRST ? (nat_order(EPI, SF32) ? 4 * MI : 2 * MI) : 0;
+  constexpr int NSTORE_ALL = RAJNI_GEMM_RELAX_FIRST ? (nat_order(EPI, SF32) ? 4 * MI : 2 * MI) * NH : 0;
+  constexpr int NSTORE = NSTORE_ALL < 48 ? NSTORE_ALL : 48;   // vmcnt is a 6-bit counter
   bool prev_full = false;          // the previous tile of this workgroup was interior
 
   while (true) {
@@ -727,9 +751,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
     const bool more = vn < p.total_tiles;
     pre.valid = false;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
       // the DMA of step kt loads K-tile kt+NS; from kt = nk-NS on that is the NEXT tile's K-tile
@@ -737,7 +763,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       if (kt == nk - NS && more) advance(tile, xcd_tile_of(vn, p.total_tiles));
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
-      if (kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
+      if (NH == 1 && kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
       half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
       if (NSTORE > 0 && kt == 0 && prev_full) wait_step<WBASE + NSTORE>();
@@ -748,12 +774,16 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_tn_stream(const GemmParams p
       st = st1;
     }
 #ifdef RAJNI_GEMM_STAMPS
-    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][MI - 1][3]));
+    asm volatile("" :: "v"(acc[0][0][0][0]), "v"(acc[NH - 1][3][MI - 1][3]));
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
+    // (written out, not a loop over h: a loop here - even one fully unrolled later - changes the order hipcc
+    // optimises in and costs the eight-wave instantiations 10-20 VGPRs, i.e. spills in the GELU epilogue)
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc[0], m0 + wm * (MI * 16), n0 + wn * NH * 64, l15, g, pre, m_lo, inter);
+    if constexpr (NH == 2)
+      epilogue_tile<EPI, SF32, MI, W8>(p, acc[1], m0 + wm * (MI * 16), n0 + wn * NH * 64 + 64, l15, g, pre, m_lo, inter);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1094,14 +1124,29 @@ inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes) {
   return (tiles_n + blocks - 1) / blocks;
 }
 
+int g_balance_grid = 0;   // tuning hook: 1 = as few workgroups as finish in the same number of rounds
+// persistent grid: one workgroup per CU; balanced: ceil(tiles / rounds) rounded up to whole XCD groups
+inline int stream_grid(int total_tiles) {
+  if (total_tiles <= g_num_cus) return total_tiles;
+  if (!g_balance_grid) return g_num_cus;
+  const int rounds = (total_tiles + g_num_cus - 1) / g_num_cus;
+  const int g = ((total_tiles + rounds - 1) / rounds + 7) & ~7;
+  return g < g_num_cus ? g : g_num_cus;
+}
+
 template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.stamps = rajni_g_stamps;
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
-  if ((mode == 4 || mode == 5) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
-  if (mode == 4 && p.K < 192) mode = 1;   // the persistent streams need >= NS + 1 K steps
+  if ((mode == 4 || mode == 5 || mode == 6) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
+#ifdef RAJNI_GEMM_WIDE4
+  if (mode == 6 && (ALOAD != ALOAD_PLAIN || W8)) mode = 4;   // the 4-wave tiling is built for plain bf16 operands
+#else
+  if (mode == 6) mode = 4;   // experiment, not built by default (see the note at mode 6 below)
+#endif
+  if ((mode == 4 || mode == 6) && p.K < 192) mode = 1;   // the persistent streams need >= NS + 1 K steps
   if (mode == 5 && p.K < 256) mode = 1;
   if (mode == 0) {
     // measured on ViT-B shapes (tools/gemm_bench.py, tools/proj_probe.py, profiles/):
@@ -1113,7 +1158,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     else if (p.M >= 1024 && p.K >= 256) mode = 5;
     else mode = 1;
   }
-  static bool attr[5] = {false, false, false, false, false};   // [2] small, [3] wide, [4] mid
+  static bool attr[6] = {false, false, false, false, false, false};   // [2] small, [3] wide, [4] mid, [5] wide4
   // algorithmic bytes: X + W + output (+ the residual rows read), fp32 where the residual stream is fp32
   constexpr double ysz = (SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH)) ? 4.0 : 2.0;
   constexpr double rsz = EPI == EPI_RESID ? (SF32 ? 4.0 : 2.0) : 0.0;
@@ -1127,14 +1172,30 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);   // fp8 W: same blocks as bf16 (measured)
-    const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;   // persistent: one workgroup per CU
+    const int grid = stream_grid(p.total_tiles);
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+#ifdef RAJNI_GEMM_WIDE4
+  // Experiment (-DRAJNI_GEMM_WIDE4, tiling 6): the same 256x256x64 tile on FOUR waves of 128x128 (NH = 2; 256
+  // VGPRs + 256 AGPRs, one wave per SIMD - the shape of hipBLASLt's MT256x256x64 kernel).  A third fewer LDS
+  // fragment bytes per MFMA, but with this schedule it is no faster: 8192^3 1253 vs 1211 TFLOP/s, QKV shape
+  // 909 vs 1143 (the epilogue of 256 outputs per lane is exposed at K = 768), K = 3072 1196 vs 1193.
+  } else if (mode == 6) {
+    if constexpr (ALOAD == ALOAD_PLAIN && !W8) {
+      using C = wide::Cfg<4, 2, false, 4>;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 2, 8, 2, false, 2>, C::LDS_BYTES, attr[5])) != RAJNI_OK) return rc;
+      p.tiles_n = (p.N + 255) / 256;
+      p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
+      p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);
+      const int grid = stream_grid(p.total_tiles);
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 2, 8, 2, false, 2>), dim3(grid), dim3(256), C::LDS_BYTES, s, p);
+    }
+#endif
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2);
-    const int grid = p.total_tiles < g_num_cus ? p.total_tiles : g_num_cus;
+    const int grid = stream_grid(p.total_tiles);
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {
     constexpr int lds = small::LDS_BYTES;
@@ -1150,6 +1211,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
+extern "C" void rajni_debug_set_gemm_balanced_grid(int on) { g_balance_grid = on; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }
 
