@@ -78,7 +78,8 @@ int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int
 /* ---- a8: softmax(q k^T * scale) v on the kept tokens                      attention.py:46-54 ----
  * qkv [B,n_src,3*H*D]; keep_idx [B,np] int32 or NULL (NULL: identity, np == n_src - the unpruned
  * block of model.py:62).  The row gather of attention.py:42-43 is fused into the tile loads.
- * out [B,np,H*D].  D must be 64. */
+ * out [B,np,H*D].  D % 8 == 0, 8 <= D <= 128 (D = 64 has the tuned
+ * kernels; other head dims take a general MFMA kernel). */
 int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                     int H, int D, float scale, int dtype, rajni_stream_t stream);
 /* test hook: 0 = choose by np (default: persistent full-row kernel for np <= 256), 1 = chunked online-softmax

@@ -636,6 +636,206 @@ __global__ void __launch_bounds__(256) attn_f32_d64(const AttnArgsF32 a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Any head dim D with D % 8 == 0, D <= 128 (ViT-H 80, ViT-g 88, EVA/SigLIP 72...128, small heads 32/48): the
+// general path beside the tuned D = 64 kernels above.  Same orientation - S^T = K Q^T, O^T += V^T P^T, the
+// exponentiated S^T accumulator is the next MFMA's B operand - on v_mfma_f32_16x16x16_bf16, whose contraction
+// step of 16 fits every such D after zero-padding to DP = 16 * ceil(D / 16) in LDS.  Workgroup = 4 waves x 16
+// query rows of one (image, head); keys in chunks of 64: K row-major, V transposed, both padded to
+// conflict-free strides; online softmax per chunk in fp32 (per-query state is per-lane, replicated over
+// the four lane groups).  Operand layouts (lane l: r = l % 16, g = l / 16, j = 0..3):
+//   A[i = r][k = 4g + j]   B[k = 4g + j][n = r]   C[i = 4g + j][n = r]
+// ---------------------------------------------------------------------------------------------
+constexpr int AG_KSTRIDE = 136;   // bf16 per K row in LDS (128 + 8): 16 rows x 2 lane groups hit 64 distinct banks
+constexpr int AG_VSTRIDE = 68;    // bf16 per V^T row (64 keys + 4)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__global__ void __launch_bounds__(256) attn_bf16_dgen(const AttnArgs a, int D) {
+  __shared__ __attribute__((aligned(16))) bf16_t sk[64 * AG_KSTRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_t svt[128 * AG_VSTRIDE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int np = a.np, C = a.H * D, C3 = 3 * C;
+  const int ND = (D + 15) >> 4;                 // 16-wide d blocks (last one zero-padded)
+  const bf16_t* img = a.qkv + (long)b * a.n_src * C3 + head * D;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+
+  int q = blockIdx.x * 64 + wave * 16 + r;
+  const bool valid = q < np;
+  if (!valid) q = np - 1;
+  s16x4_t qf[8];                                 // B operand of S^T: Q[q][16 kd + 4g + j]
+  {
+    const int srow = idx ? idx[q] : q;
+    const bf16_t* qp = img + (long)srow * C3;
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) {
+      qf[kd] = s16x4_t{0, 0, 0, 0};
+      const int d0 = 16 * kd + 4 * g;
+      if (kd < ND && d0 < D) qf[kd] = *reinterpret_cast<const s16x4_t*>(qp + d0);   // D % 4 == 0: whole or nothing
+    }
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int db = 0; db < 8; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+  const int chunks8 = 2 * ND;                   // 8-element pieces per staged row (covering DP)
+
+  for (int c0 = 0; c0 < np; c0 += 64) {
+    __syncthreads();                            // everyone is done reading the previous chunk
+    for (int item = tid; item < 64 * chunks8; item += 256) {
+      const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
+      const int t = c0 + row;
+      uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+      if (t < np && d0 < D) {                   // D % 8 == 0: a piece is whole or padding
+        const int srow = idx ? idx[t] : t;
+        const bf16_t* rp = img + (long)srow * C3 + d0;
+        kq = *reinterpret_cast<const uint4*>(rp + C);
+        vq = *reinterpret_cast<const uint4*>(rp + 2 * C);
+      }
+      *reinterpret_cast<uint4*>(sk + row * AG_KSTRIDE + d0) = kq;
+      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vq);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) svt[(d0 + j) * AG_VSTRIDE + row] = ve[j];
+    }
+    __syncthreads();
+
+    f32x4 st[4];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kd = 0; kd < 8; ++kd)
+        if (kd < ND) {
+          const s16x4_t ka = *reinterpret_cast<const s16x4_t*>(sk + (16 * kb + r) * AG_KSTRIDE + 16 * kd + 4 * g);
+          st[kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[kd], st[kb], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = c0 + 16 * kb + 4 * g + j;
+        const float v = key < np ? st[kb][j] * a.c : -INFINITY;   // log2 domain
+        st[kb][j] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);       // finite: every chunk holds at least one real key
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    s16x4_t pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      float pv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pv[j] = __builtin_amdgcn_exp2f(st[kb][j] - m_new);
+        psum += pv[j];
+      }
+      const unsigned lo = pack2bf(pv[0], pv[1]), hi = pack2bf(pv[2], pv[3]);
+      pf[kb] = __builtin_bit_cast(s16x4_t, make_uint2(lo, hi));
+    }
+    l_part = fmaf(l_part, alpha, psum);
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+      if (db < ND) {
+        o[db] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const s16x4_t va = *reinterpret_cast<const s16x4_t*>(svt + (16 * db + r) * AG_VSTRIDE + 16 * kb + 4 * g);
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[kb], o[db], 0, 0, 0);
+        }
+      }
+  }
+  float l = l_part + __shfl_xor(l_part, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (valid) {
+    const float inv = 1.0f / l;
+    bf16_t* op = a.out + ((long)b * np + q) * C + head * D;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      const int d0 = 16 * db + 4 * g;
+      if (db < ND && d0 < D)
+        *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[db][0] * inv, o[db][1] * inv), pack2bf(o[db][2] * inv, o[db][3] * inv));
+    }
+  }
+}
+
+// fp32 models, any head dim D % 4 == 0, D <= 128: the VALU kernel of attn_f32_d64 with DQ = D / 4 dims per lane
+// (DQM = compile-time bound of DQ) and 32-key chunks.
+template <int DQM>
+__global__ void __launch_bounds__(256) attn_f32_dgen(const AttnArgsF32 a, int D) {
+  __shared__ __attribute__((aligned(16))) float sk[32 * 4 * DQM];
+  __shared__ __attribute__((aligned(16))) float sv[32 * 4 * DQM];
+  const int tid = threadIdx.x;
+  const int qrow = tid >> 2, pt = tid & 3;           // 64 query rows x 4 lanes
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int np = a.np, C = a.H * D, C3 = 3 * C, DQ = D >> 2, D4 = D >> 2;
+  const float* img = a.qkv + (long)b * a.n_src * C3 + head * D;
+  const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
+  int q = blockIdx.x * 64 + qrow;
+  const bool valid = q < np;
+  if (!valid) q = np - 1;
+  float qv[DQM], o[DQM];
+  {
+    const int srow = idx ? idx[q] : q;
+    const float* qp = img + (long)srow * C3 + pt * DQ;
+#pragma unroll
+    for (int e = 0; e < DQM; ++e) {
+      qv[e] = e < DQ ? qp[e] : 0.f;
+      o[e] = 0.f;
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int c0 = 0; c0 < np; c0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * D4; e += 256) {       // float4 pieces of 32 K rows and 32 V rows
+      const int row = e / D4, c4 = e - row * D4;
+      const int t = c0 + row;
+      float4 kq = make_float4(0, 0, 0, 0), vq = make_float4(0, 0, 0, 0);
+      if (t < np) {
+        const int srow = idx ? idx[t] : t;
+        const float* rp = img + (long)srow * C3 + c4 * 4;
+        kq = *reinterpret_cast<const float4*>(rp + C);
+        vq = *reinterpret_cast<const float4*>(rp + 2 * C);
+      }
+      reinterpret_cast<float4*>(sk)[e] = kq;
+      reinterpret_cast<float4*>(sv)[e] = vq;
+    }
+    __syncthreads();
+    const int nk = np - c0 < 32 ? np - c0 : 32;
+    for (int j = 0; j < nk; ++j) {
+      const float* kr = sk + j * D + pt * DQ;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < DQM; ++e)
+        if (e < DQ) d = fmaf(qv[e], kr[e], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      const float sc = d * a.c;
+      const float m_new = fmaxf(m_run, sc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float pj = __builtin_amdgcn_exp2f(sc - m_new);
+      l_run = fmaf(l_run, alpha, pj);
+      m_run = m_new;
+      const float* vr = sv + j * D + pt * DQ;
+#pragma unroll
+      for (int e = 0; e < DQM; ++e)
+        if (e < DQ) o[e] = fmaf(o[e], alpha, pj * vr[e]);
+    }
+  }
+  if (valid) {
+    const float inv = 1.0f / l_run;
+    float* op = a.out + ((long)b * np + q) * C + head * D + pt * DQ;
+#pragma unroll
+    for (int e = 0; e < DQM; ++e)
+      if (e < DQ) op[e] = o[e] * inv;
+  }
+}
+
 int g_force_attn = 0;  // 0 auto (persistent), 1 chunked online-softmax kernel, 2 one-shot full-row kernel (tests)
 
 template <int NSUB>
@@ -668,30 +868,30 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// CLS-query attention: out[b, h*64 + d] = softmax_n(q[b,0,h] . k[b,n,h] * scale) . v[b,n,h,d] over all
+// CLS-query attention: out[b, h*D + d] = softmax_n(q[b,0,h] . k[b,n,h] * scale) . v[b,n,h,d] over all
 // N tokens - the only attention row the classifier head can see in the LAST block (model.py:65-66 reads
 // x[:, 0]).  One wave per (image, head): lanes over keys for the logits, lanes over d for the output.
-// fp32 math on the stored activations (P is not rounded to bf16 here).
+// fp32 math on the stored activations (P is not rounded to bf16 here).  D % 8 == 0, D <= 128.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(64) attn_cls_d64(const T* qkv, T* out, int N, int H, float c) {
-  extern __shared__ __attribute__((aligned(16))) float prob[];   // [N]
+__global__ void __launch_bounds__(64) attn_cls_kernel(const T* qkv, T* out, int N, int H, int D, float c) {
+  extern __shared__ __attribute__((aligned(16))) float cls_sm[];
+  float* qs = cls_sm;                // [D]
+  float* prob = cls_sm + D;          // [N]
   const int lane = threadIdx.x, head = blockIdx.x, b = blockIdx.y;
-  const int C = H * 64, C3 = 3 * C;
-  const T* img = qkv + (long)b * N * C3 + head * 64;
-  float q[64];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) load8<T>(img + 8 * i, q + 8 * i);        // same address in every lane: broadcast
+  const int C = H * D, C3 = 3 * C;
+  const T* img = qkv + (long)b * N * C3 + head * D;
+  for (int d = lane; d < D; d += 64) qs[d] = ld1(img + d);
+  __syncthreads();
   float mx = -INFINITY;
   for (int n = lane; n < N; n += 64) {
     const T* kr = img + (long)n * C3 + C;
     float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < (D >> 3); ++i) {
       float kf[8];
       load8<T>(kr + 8 * i, kf);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot = fmaf(q[8 * i + j], kf[j], dot);
+      for (int j = 0; j < 8; ++j) dot = fmaf(qs[8 * i + j], kf[j], dot);
     }
     dot *= c;                                                             // log2 domain
     prob[n] = dot;
@@ -706,30 +906,34 @@ __global__ void __launch_bounds__(64) attn_cls_d64(const T* qkv, T* out, int N, 
   }
   sum = wave_sum(sum);
   __syncthreads();
-  float acc = 0.f;                                                        // lane = d
-  const T* vc = img + 2 * C + lane;
-  for (int n = 0; n < N; ++n) acc = fmaf(prob[n], ld1(vc + (long)n * C3), acc);
-  st1(out + (long)b * C + head * 64 + lane, acc / sum);
+  for (int d = lane; d < D; d += 64) {                                    // lane = d
+    float acc = 0.f;
+    const T* vc = img + 2 * C + d;
+    for (int n = 0; n < N; ++n) acc = fmaf(prob[n], ld1(vc + (long)n * C3), acc);
+    st1(out + (long)b * C + head * D + d, acc / sum);
+  }
 }
 
 int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,
                          hipStream_t s) {
-  RAJNI_REQUIRE(qkv && out && D == 64 && B > 0 && H > 0 && N > 0 && B <= 65535, RAJNI_ERR_INVALID,
-                "attention_cls: bad arguments");
+  RAJNI_REQUIRE(qkv && out && D >= 8 && D <= 128 && D % 8 == 0 && B > 0 && H > 0 && N > 0 && B <= 65535 &&
+                (size_t)(N + D) * sizeof(float) <= 64 * 1024, RAJNI_ERR_INVALID, "attention_cls: bad arguments");
   const float c = scale * 1.4426950408889634f;
+  const size_t lds = (size_t)(N + D) * sizeof(float);
   ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)N * D, 2.0 * B * (double)N * H * D * (dtype == RAJNI_F32 ? 4.0 : 2.0));
   if (dtype == RAJNI_F32)
-    hipLaunchKernelGGL(attn_cls_d64<float>, dim3(H, B), dim3(64), N * sizeof(float), s, (const float*)qkv, (float*)out, N, H, c);
+    hipLaunchKernelGGL(attn_cls_kernel<float>, dim3(H, B), dim3(64), lds, s, (const float*)qkv, (float*)out, N, H, D, c);
   else
-    hipLaunchKernelGGL(attn_cls_d64<bf16_t>, dim3(H, B), dim3(64), N * sizeof(float), s, (const bf16_t*)qkv, (bf16_t*)out, N, H, c);
-  RAJNI_CHECK_LAUNCH("attn_cls_d64");
+    hipLaunchKernelGGL(attn_cls_kernel<bf16_t>, dim3(H, B), dim3(64), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, H, D, c);
+  RAJNI_CHECK_LAUNCH("attn_cls_kernel");
   return RAJNI_OK;
 }
 
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, int dtype, hipStream_t s) {
   RAJNI_REQUIRE(qkv && out, RAJNI_ERR_INVALID, "rajni_attention: null pointer");
-  RAJNI_REQUIRE(D == 64, RAJNI_ERR_UNSUPPORTED, "rajni_attention: head dim %d not built (64 only)", D);
+  RAJNI_REQUIRE(D >= 8 && D <= 128 && D % 8 == 0, RAJNI_ERR_UNSUPPORTED,
+                "rajni_attention: head dim %d not supported (multiples of 8 up to 128)", D);
   RAJNI_REQUIRE(B > 0 && H > 0 && np > 0 && n_src >= np, RAJNI_ERR_INVALID,
                 "rajni_attention: bad shape B=%d H=%d np=%d n_src=%d", B, H, np, n_src);
   RAJNI_REQUIRE(keep_idx != nullptr || np == n_src, RAJNI_ERR_INVALID,
@@ -740,8 +944,11 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
     f.qkv = (const float*)qkv; f.idx = keep_idx; f.out = (float*)out;
     f.n_src = n_src; f.np = np; f.H = H; f.c = scale * 1.4426950408889634f;
     ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)np * np * D, 4.0 * B * (double)np * H * D * 4.0);
-    hipLaunchKernelGGL(attn_f32_d64, dim3((np + 63) / 64, H, B), dim3(256), 0, s, f);
-    RAJNI_CHECK_LAUNCH("attn_f32_d64");
+    const dim3 grid((np + 63) / 64, H, B);
+    if (D == 64) hipLaunchKernelGGL(attn_f32_d64, grid, dim3(256), 0, s, f);
+    else if (D < 64) hipLaunchKernelGGL(attn_f32_dgen<16>, grid, dim3(256), 0, s, f, D);
+    else hipLaunchKernelGGL(attn_f32_dgen<32>, grid, dim3(256), 0, s, f, D);
+    RAJNI_CHECK_LAUNCH("attn_f32");
     return RAJNI_OK;
   }
   RAJNI_REQUIRE(dtype == RAJNI_BF16, RAJNI_ERR_INVALID, "rajni_attention: bad dtype %d", dtype);
@@ -754,7 +961,9 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   const double bytes = 2.0 * B * (double)np * H * D * 4.0;
   ProfScope prof(KC_ATTENTION, s, flops, bytes);
   const int nsub = (np + 31) / 32;
-  if (nsub <= 8 && g_force_attn != 1) {
+  if (D != 64) {
+    hipLaunchKernelGGL(attn_bf16_dgen, dim3((np + 63) / 64, H, B), dim3(256), 0, s, a, D);
+  } else if (nsub <= 8 && g_force_attn != 1) {
     int rc = RAJNI_OK;
     switch (nsub) {
       case 1: rc = launch_full<1>(a, B, s); break;

@@ -46,8 +46,8 @@ __global__ void carry_scores_kernel(const T* scores, const int* idx, T* out, int
 int check_plan(const rajni_vit_plan& p) {
   RAJNI_REQUIRE(p.dtype == RAJNI_BF16 || p.dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_vit_forward: bad dtype %d", p.dtype);
   RAJNI_REQUIRE(p.B > 0 && p.depth > 0 && p.blocks != nullptr, RAJNI_ERR_INVALID, "rajni_vit_forward: bad plan");
-  RAJNI_REQUIRE(p.C == p.H * p.D && p.D == 64, RAJNI_ERR_UNSUPPORTED,
-                "rajni_vit_forward: need C == H*D and head dim 64 (C=%d H=%d D=%d)", p.C, p.H, p.D);
+  RAJNI_REQUIRE(p.C == p.H * p.D && p.D >= 8 && p.D <= 128 && p.D % 8 == 0, RAJNI_ERR_UNSUPPORTED,
+                "rajni_vit_forward: need C == H*D and a head dim that is a multiple of 8 up to 128 (C=%d H=%d D=%d)", p.C, p.H, p.D);
   RAJNI_REQUIRE(p.C % 64 == 0 && p.hidden % 64 == 0, RAJNI_ERR_UNSUPPORTED,
                 "rajni_vit_forward: C and hidden must be multiples of 64");
   RAJNI_REQUIRE(p.patch_w && p.cls_token && p.pos_embed && p.norm_w && p.norm_b && p.head_w,

@@ -62,8 +62,11 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   if (COMPUTE) {
     const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * N * 3 * C;
     const int LP = D >> 3;             // lanes per 2*D-byte head row
-    const int sub = tid & (LP - 1);
-    const int grp = tid / LP, ngrp = SS_THREADS / LP;
+    // head dims 32 / 64 / 128: LP is 4 / 8 / 16 and the lanes of a head row are summed by DPP adds; any other
+    // D % 8 == 0 (80, 96, 72 ...) takes the plain forms below (one lane per (token, head) dot product, serial norms)
+    const bool pow2 = LP == 4 || LP == 8 || LP == 16;
+    const int sub = tid % LP;
+    const int grp = tid / LP, ngrp = SS_THREADS / LP;   // threads past ngrp * LP sit the head-row passes out
 
     // ---- CLS query row -> LDS (importance.py:18)
     for (int c = tid; c < (C >> 3); c += SS_THREADS) {
@@ -79,7 +82,20 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     // chunks of a head sit in LP consecutive lanes and are summed with DPP adds (ds_bpermute shuffles and an
     // integer division per item made this loop 34 of the kernel's 60 us).  U loads in flight per thread.
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
-    {
+    if (!pow2) {
+      for (int item = tid; item < N * H; item += SS_THREADS) {   // consecutive lanes = consecutive heads of a row
+        const int n = item / H, h = item - n * H;
+        const T* kp = base + (long)n * 3 * C + C + h * D;
+        float dot = 0.f;
+        for (int c = 0; c < LP; ++c) {
+          float kf[8];
+          load8<T>(kp + c * 8, kf);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot = fmaf(kf[j], qcls[h * D + c * 8 + j], dot);
+        }
+        region[h * N + n] = dot * inv_sqrt_d;
+      }
+    } else {
       constexpr int U = 8;
       const int CP = C >> 3;
       const int dn = SS_THREADS / CP, dc = SS_THREADS - dn * CP;   // item index += SS_THREADS
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
 
     // ---- vbar[n][:] = mean_h v[n,h,:]   (importance.py:24)
     const float inv_h = 1.0f / (float)H;
-    for (int n = grp; n < N; n += ngrp) {
+    for (int n = grp < ngrp ? grp : N; n < N; n += ngrp) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const T* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
       for (int h0 = 0; h0 < H; h0 += 12) {     // 12 head rows in flight; summed in head order (fixed tree)
@@ -154,10 +170,10 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     __syncthreads();
     // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
     {
-      const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;
+      const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;   // threads past nparts * D idle
       float s = 0.f;
-      for (int n = prt; n < N; n += nparts) s += region[n * D + d];
-      part[prt * D + d] = s;
+      for (int n = prt < nparts ? prt : N; n < N; n += nparts) s += region[n * D + d];
+      if (prt < nparts) part[prt * D + d] = s;
       __syncthreads();
       if (tid < D) {
         float t = 0.f;
@@ -167,6 +183,16 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       __syncthreads();
     }
     // ---- ||vbar[n] - mean||_2   (importance.py:27)
+    if (!pow2) {
+      for (int n = tid; n < N; n += SS_THREADS) {
+        float ss = 0.f;
+        for (int d = 0; d < D; ++d) {
+          const float dlt = region[n * D + d] - mean[d];
+          ss = fmaf(dlt, dlt, ss);
+        }
+        sc[n] = sqrtf(ss);
+      }
+    } else
     for (int n = grp; n < N; n += ngrp) {
       const float* src = region + n * D + sub * 8;
       const float* mp = mean + sub * 8;
@@ -283,8 +309,8 @@ int launch_score_select(const void* qkv, const void* scores_in, int B, int N, in
   a.scores_out = scores_out; a.keep_idx = keep_idx; a.next_scores = next_scores;
   size_t lds;
   if (qkv != nullptr) {
-    RAJNI_REQUIRE(D == 32 || D == 64 || D == 128, RAJNI_ERR_UNSUPPORTED,
-                  "importance: head dim %d not supported (32/64/128)", D);
+    RAJNI_REQUIRE(D >= 8 && D <= 128 && D % 8 == 0, RAJNI_ERR_UNSUPPORTED,
+                  "importance: head dim %d not supported (multiples of 8 up to 128)", D);
     RAJNI_REQUIRE(H > 0, RAJNI_ERR_INVALID, "importance: H must be positive");
     a.qkv = qkv; a.H = H; a.D = D;
     lds = ss_lds_bytes(N, H, D);

@@ -213,10 +213,11 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref, refw = load_reference()
-    importance_cases(refw)
-    selection_cases()
-    evaluate_cases(ref)
-    only = sys.argv[1:]
+    only = sys.argv[1:]          # forward case names: regenerate just those
+    if not only:
+        importance_cases(refw)
+        selection_cases()
+        evaluate_cases(ref)
     cases = [
         ("micro_fp32", "vit_micro_patch16_64", MICRO_SCHEDULE, 4, 0, 0.08, 0.02, torch.float32),
         ("tiny224_fp32", "vit_tiny_patch16_224", README_SCHEDULE, 2, 1, 0.06, 0.02, torch.float32),
@@ -224,6 +225,7 @@ def main():
         ("base224_bf16", "vit_base_patch16_224", README_SCHEDULE, 2, 2, 0.04, 0.02, torch.bfloat16),
         ("deit3_fp32", "deit3_base_patch16_224", README_SCHEDULE, 2, 3, 0.04, 0.02, torch.float32),
         ("large384_fp32", "vit_large_patch16_384", AGGRESSIVE_L384, 1, 4, 0.03, 0.02, torch.float32),
+        ("microd80_fp32", "vit_micro_d80_patch16_64", MICRO_SCHEDULE, 3, 5, 0.08, 0.02, torch.float32),
     ]
     for c in cases:
         if only and c[0] not in only:

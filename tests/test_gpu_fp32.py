@@ -113,7 +113,7 @@ def test_layernorm_and_patch_embed_f32():
     close(host(xx), want, 3e-6, "patch embed f32")
 
 
-@pytest.mark.parametrize("name", ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32"])
+@pytest.mark.parametrize("name", ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32"])
 def test_forward_f32_equals_reference(name):
     """Free-running fp32 forward vs the reference's fp32 run: same keep_idx (bit exact wherever the
     reference's own boundary gap exceeds fp32 noise), same token_counts, logits within 1e-3."""
