@@ -131,12 +131,16 @@ void rajni_debug_set_gemm_balanced_grid(int on);
 void rajni_debug_set_gemm_stamps(void* buf);
 
 /* ---- a12: patch-embed + CLS + pos-embed                                    model.py:34-37 ----
- * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad256), Cin*P*P] (k order c,ky,kx),
- * bias fp32 [C]; cls [C]; pos [(1 or 0)+(S/P)^2, C] (`pos_has_cls`=0 is timm no_embed_class:
- * SURVEY B3); x is written as fp32 when x_f32 != 0.  The im2col is fused into the GEMM's tile loads.  P % 8 == 0, S % P == 0. */
+ * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad256), ceil64(Cin*P*P)] (k order c,ky,kx,
+ * zero-padded columns), bias fp32 [C]; cls [C]; pos [(1 or 0)+(S/P)^2, C] (`pos_has_cls`=0 is timm
+ * no_embed_class: SURVEY B3); x is written as fp32 when x_f32 != 0.  S % P == 0.  For a power-of-two P >= 8
+ * with S % 8 == 0 and Cin*P*P % 64 == 0 the im2col is fused into the GEMM's tile loads and no workspace is
+ * needed; any other patch size (14: ViT-L/14, ViT-H/14, DINOv2) materialises the zero-padded column matrix in
+ * `workspace` (16-byte aligned, >= rajni_patch_embed_workspace_bytes(...), which is 0 for the fused case). */
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                       const void* pos, int pos_has_cls, void* x, int x_f32, int B, int Cin, int S,
-                      int P, int C, int dtype, rajni_stream_t stream);
+                      int P, int C, int dtype, void* workspace, size_t workspace_bytes, rajni_stream_t stream);
+size_t rajni_patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype);
 
 /* ---- a11-a16: the whole RAJNIViTWrapper.forward                            model.py:30-69 ---- */
 typedef struct {

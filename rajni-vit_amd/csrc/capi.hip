@@ -54,7 +54,7 @@ ProfScope::~ProfScope() {
 
 extern "C" {
 
-int rajni_abi_version(void) { return 3; }
+int rajni_abi_version(void) { return 4; }
 const char* rajni_last_error(void) { return g_err; }
 
 int rajni_device_check(void) {
@@ -135,10 +135,13 @@ int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {
 
 int rajni_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                       const void* pos, int pos_has_cls, void* x, int x_f32, int B, int Cin, int S,
-                      int P, int C, int dtype, rajni_stream_t stream) {
+                      int P, int C, int dtype, void* workspace, size_t workspace_bytes, rajni_stream_t stream) {
   NEED_DTYPE("rajni_patch_embed");
   return launch_patch_embed(images, w, bias, cls, pos, pos_has_cls, x, x_f32, B, Cin, S, P, C, dtype,
-                            (hipStream_t)stream);
+                            workspace, workspace_bytes, (hipStream_t)stream);
+}
+size_t rajni_patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype) {
+  return patch_embed_workspace_bytes(B, Cin, S, P, dtype);
 }
 
 void rajni_profile_enable(unsigned mask) { g_prof_mask = mask; }

@@ -116,7 +116,8 @@ extern unsigned long long* rajni_g_stamps;
 int launch_linear(const rajni_linear_args& a, hipStream_t s);
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                        const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
-                       int P, int C, int dtype, hipStream_t s);
+                       int P, int C, int dtype, void* ws, size_t ws_bytes, hipStream_t s);
+size_t patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype);   // 0: im2col fused into the GEMM loads
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
                      int C, float eps, int x_f32, int dtype, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,

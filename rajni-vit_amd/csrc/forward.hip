@@ -13,8 +13,8 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-  char *xa, *xb, *xn, *qkv, *att, *hid, *clsn, *scf;
-  size_t total;
+  char *xa, *xb, *xn, *qkv, *att, *hid, *clsn, *scf, *cols;
+  size_t total, cols_bytes;
 };
 
 Workspace carve(const rajni_vit_plan& p) {
@@ -27,9 +27,11 @@ Workspace carve(const rajni_vit_plan& p) {
   const size_t oqkv = take(rows * 3 * p.C * es), oatt = take(rows * p.C * es);
   const size_t ohid = take(rows * p.hidden * es), ocls = take((size_t)p.B * p.C * es);
   const size_t oscf = take(rows * es);
+  w.cols_bytes = patch_embed_workspace_bytes(p.B, p.in_chans, p.img_size, p.patch_size, p.dtype);   // 0 when fused
+  const size_t ocols = take(w.cols_bytes);
   char* base = (char*)p.workspace;
   w.xa = base + oxa; w.xb = base + oxb; w.xn = base + oxn; w.qkv = base + oqkv; w.att = base + oatt;
-  w.hid = base + ohid; w.clsn = base + ocls; w.scf = base + oscf;
+  w.hid = base + ohid; w.clsn = base + ocls; w.scf = base + oscf; w.cols = base + ocols;
   w.total = off;
   return w;
 }
@@ -81,7 +83,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
   const int dt = p.dtype;
   const int sf32 = (dt == RAJNI_BF16 && !p.resid_bf16) ? 1 : 0;  // bf16 model with an fp32 residual stream
   rc = launch_patch_embed(images, p.patch_w, p.patch_b, p.cls_token, p.pos_embed, p.pos_has_cls,
-                          w.xa, sf32, B, p.in_chans, p.img_size, p.patch_size, C, dt, s);
+                          w.xa, sf32, B, p.in_chans, p.img_size, p.patch_size, C, dt, w.cols, w.cols_bytes, s);
   if (rc != RAJNI_OK) return rc;
 
   char* cur = w.xa;

@@ -1275,31 +1275,91 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   }
 }
 
+// the fused im2col loader reads 16-byte runs of a patch row with shifts: power-of-two patches of >= 8 pixels
+// whose K = Cin*P*P is whole K steps.  Everything else (P = 14: ViT-L/14, ViT-H/14, DINOv2, CLIP) goes through a
+// materialised, zero-padded column matrix.
+static bool patch_fused(int Cin, int S, int P) {
+  return P >= 8 && (P & (P - 1)) == 0 && S % 8 == 0 && (Cin * P * P) % 64 == 0;
+}
+size_t patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype) {
+  if (P <= 0 || S <= 0 || S % P != 0 || patch_fused(Cin, S, P)) return 0;
+  const size_t kpad = ((size_t)Cin * P * P + 63) / 64 * 64, gw = S / P;
+  return (size_t)B * gw * gw * kpad * (dtype == RAJNI_F32 ? 4 : 2);
+}
+// cols[m, k] = images[b, c, gy*P + py, gx*P + px] for k = (c*P + py)*P + px < Cin*P*P, 0 for the padding;
+// one thread = 8 consecutive k of one patch row (one 16-byte store for bf16)
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_kernel(const T* img, T* cols, int Cin, int S, int P, int gw, int kpad, long total8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int k8 = kpad >> 3;
+  const long m = i / k8;
+  const int k0 = (int)(i - m * k8) * 8;
+  const int npatch = gw * gw;
+  const int b = (int)(m / npatch), pp = (int)(m - (long)b * npatch);
+  const int gy = pp / gw, gx = pp - gy * gw;
+  const int K = Cin * P * P;
+  T v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    T e = T(0);
+    if (k < K) {
+      const int c = k / (P * P), r = k - c * P * P, py = r / P, px = r - py * P;
+      e = img[(((long)b * Cin + c) * S + gy * P + py) * S + gx * P + px];
+    }
+    v[j] = e;
+  }
+  T* dst = cols + m * kpad + k0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = v[j];
+}
+
 int launch_patch_embed(const void* images, const void* w, const float* bias, const void* cls,
                        const void* pos, int pos_has_cls, void* x, int out_f32, int B, int Cin, int S,
-                       int P, int C, int dtype, hipStream_t s) {
+                       int P, int C, int dtype, void* ws, size_t ws_bytes, hipStream_t s) {
   RAJNI_REQUIRE(images && w && cls && pos && x, RAJNI_ERR_INVALID, "rajni_patch_embed: null pointer");
-  RAJNI_REQUIRE(P >= 8 && (P & (P - 1)) == 0 && S % P == 0 && S % 8 == 0, RAJNI_ERR_UNSUPPORTED,
-                "rajni_patch_embed: patch size must be a power of two >= 8 dividing the image (P=%d S=%d)", P, S);
-  const int K = Cin * P * P;
-  RAJNI_REQUIRE(K % 64 == 0 && C % 8 == 0, RAJNI_ERR_UNSUPPORTED,
-                "rajni_patch_embed: Cin*P*P %% 64 == 0 and C %% 8 == 0 required");
+  RAJNI_REQUIRE(P >= 1 && S % P == 0 && B > 0 && Cin > 0, RAJNI_ERR_INVALID,
+                "rajni_patch_embed: the patch size must divide the image (P=%d S=%d)", P, S);
+  RAJNI_REQUIRE(C % 8 == 0, RAJNI_ERR_UNSUPPORTED, "rajni_patch_embed: C %% 8 == 0 required");
   RAJNI_REQUIRE(dtype == RAJNI_BF16 || dtype == RAJNI_F32, RAJNI_ERR_INVALID, "rajni_patch_embed: bad dtype %d", dtype);
-  int log2ps = 0;
-  while ((1 << log2ps) < P) ++log2ps;
+  const int K = Cin * P * P, kpad = (K + 63) / 64 * 64;
   const int gw = S / P, npatch = gw * gw;
   GemmParams p{};
-  p.X = images; p.lda = 0;
-  p.W = w; p.ldw = K;
+  p.W = w; p.ldw = kpad;
   p.bias = bias;
   p.Y = x; p.ldc = C;
-  p.M = B * npatch; p.N = C; p.K = K;
-  p.cin = Cin; p.S = S; p.log2ps = log2ps; p.gw = gw; p.npatch = npatch;
+  p.M = B * npatch; p.N = C; p.K = kpad;
+  p.gw = gw; p.npatch = npatch;
   p.pos = pos; p.pos_off = pos_has_cls ? 1 : 0;
   int rc;
-  if (dtype == RAJNI_F32) rc = f32::launch<EPI_PATCH, ALOAD_PATCH>(p, KC_GEMM_PATCH, s);
-  else rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)
-                    : launch_gemm<EPI_PATCH, ALOAD_PATCH, false>(p, KC_GEMM_PATCH, s);
+  if (patch_fused(Cin, S, P)) {
+    int log2ps = 0;
+    while ((1 << log2ps) < P) ++log2ps;
+    p.X = images; p.lda = 0;
+    p.cin = Cin; p.S = S; p.log2ps = log2ps;
+    if (dtype == RAJNI_F32) rc = f32::launch<EPI_PATCH, ALOAD_PATCH>(p, KC_GEMM_PATCH, s);
+    else rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PATCH, true>(p, KC_GEMM_PATCH, s)
+                      : launch_gemm<EPI_PATCH, ALOAD_PATCH, false>(p, KC_GEMM_PATCH, s);
+  } else {
+    const size_t need = patch_embed_workspace_bytes(B, Cin, S, P, dtype);
+    RAJNI_REQUIRE(ws != nullptr && ws_bytes >= need && (uintptr_t)ws % 16 == 0, RAJNI_ERR_INVALID,
+                  "rajni_patch_embed: patch size %d needs a %zu-byte, 16-byte aligned column workspace (got %zu)", P, need, ws_bytes);
+    {
+      ProfScope prof(KC_CLS_POS, s, 0.0, 2.0 * (double)need);
+      const long total8 = (long)B * npatch * (kpad / 8);
+      const dim3 grid((unsigned)((total8 + 255) / 256)), block(256);
+      if (dtype == RAJNI_F32)
+        hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, (const float*)images, (float*)ws, Cin, S, P, gw, kpad, total8);
+      else
+        hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)images, (bf16_t*)ws, Cin, S, P, gw, kpad, total8);
+      RAJNI_CHECK_LAUNCH("im2col_kernel");
+    }
+    p.X = ws; p.lda = kpad;
+    if (dtype == RAJNI_F32) rc = f32::launch<EPI_PATCH, ALOAD_PLAIN>(p, KC_GEMM_PATCH, s);
+    else rc = out_f32 ? launch_gemm<EPI_PATCH, ALOAD_PLAIN, true>(p, KC_GEMM_PATCH, s)
+                      : launch_gemm<EPI_PATCH, ALOAD_PLAIN, false>(p, KC_GEMM_PATCH, s);
+  }
   if (rc != RAJNI_OK) return rc;
   {
     ProfScope prof(KC_CLS_POS, s, 0.0, 6.0 * B * C);

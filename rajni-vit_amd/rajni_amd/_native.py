@@ -78,8 +78,9 @@ _SIGS = {
     "rajni_debug_set_gemm_balanced_grid": (None, [c_int]),
     "rajni_debug_force_attention": (None, [c_int]),
     "rajni_debug_set_gemm_stamps": (None, [c_void_p]),
+    "rajni_patch_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rajni_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "rajni_vit_workspace_bytes": (c_size_t, [C.POINTER(VitPlan)]),
     "rajni_vit_forward": (c_int, [C.POINTER(VitPlan), c_void_p, c_void_p, c_void_p]),
     "rajni_profile_enable": (None, [C.c_uint]),

@@ -22,14 +22,17 @@ def _dt(t: torch.Tensor) -> int:
     return nat.dtype_code(t.dtype)
 
 
-def pack_weight(w: torch.Tensor, dtype=torch.bfloat16, device=None) -> torch.Tensor:
+def pack_weight(w: torch.Tensor, dtype=torch.bfloat16, device=None, k_multiple: int = 1) -> torch.Tensor:
     """[N, K...] Linear/Conv weight -> contiguous [ceil256(N), K] in `dtype`, zero padded rows
-    (the GEMM stages whole 128- or 256-row W tiles)."""
+    (the GEMM stages whole 128- or 256-row W tiles).  `k_multiple` = 64 also zero-pads the columns to
+    whole K steps - the patch-embed weight of a patch size whose Cin*P*P is not one (3*14*14 = 588 -> 640)."""
     n = w.shape[0]
     w2 = w.detach().reshape(n, -1)
     npad = (n + 255) // 256 * 256
-    out = torch.zeros((npad, w2.shape[1]), dtype=dtype, device=device if device is not None else w.device)
-    out[:n].copy_(w2)
+    k = w2.shape[1]
+    kpad = (k + k_multiple - 1) // k_multiple * k_multiple
+    out = torch.zeros((npad, kpad), dtype=dtype, device=device if device is not None else w.device)
+    out[:n, :k].copy_(w2)
     return out
 
 
@@ -204,8 +207,13 @@ def patch_embed(images: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
     B, Cin, S, _ = images.shape
     n = (S // patch) ** 2 + 1
     x = torch.empty((B, n, embed_dim), dtype=torch.float32 if out_f32 else images.dtype, device=images.device)
+    kpad = (Cin * patch * patch + 63) // 64 * 64
+    if w_packed.shape[1] != kpad:
+        raise ValueError(f"patch_embed: weight must be packed with k_multiple=64 ([*, {kpad}]), got {tuple(w_packed.shape)}")
+    nbytes = nat.lib().rajni_patch_embed_workspace_bytes(B, Cin, S, patch, _dt(images))   # 0: im2col fused into the loads
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device) if nbytes else None
     nat.check(nat.lib().rajni_patch_embed(images.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), cls.data_ptr(),
                                           pos.data_ptr(), int(pos_has_cls), x.data_ptr(), int(out_f32), B, Cin, S, patch,
-                                          embed_dim, _dt(images), nat.stream_ptr(images.device)),
+                                          embed_dim, _dt(images), nat.ptr(ws), nbytes, nat.stream_ptr(images.device)),
               "rajni_patch_embed")
     return x

@@ -73,6 +73,9 @@ CONFIGS: Dict[str, ViTConfig] = {
     # tiny head_dim-64 model for fast parity tests (not a timm name)
     "vit_micro_patch16_64": ViTConfig(img_size=64, embed_dim=128, depth=4, num_heads=2,
                                       num_classes=10),
+    # patch 14 (ViT-L/14, ViT-H/14, DINOv2): 3*14*14 = 588 input features, not whole 64-wide K steps
+    "vit_micro_patch14_56": ViTConfig(img_size=56, patch_size=14, embed_dim=128, depth=4, num_heads=2,
+                                      num_classes=10),
     # the same with head dim 80 (ViT-H's), for the general-head-dim kernels (not a timm name)
     "vit_micro_d80_patch16_64": ViTConfig(img_size=64, embed_dim=320, depth=4, num_heads=4,
                                           num_classes=10),

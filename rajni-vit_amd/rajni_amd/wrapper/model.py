@@ -222,7 +222,7 @@ class RAJNIViTWrapper(nn.Module):
         pv = lambda v: ops.pack_vec(v, dtype, device)
         zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
         W = dict(desc=desc)
-        W["patch_w"] = pw(m.patch_embed.proj.weight)
+        W["patch_w"] = ops.pack_weight(m.patch_embed.proj.weight, dtype, device, k_multiple=64)
         W["patch_b"] = pv(m.patch_embed.proj.bias) if m.patch_embed.proj.bias is not None else zeros(desc["C"])
         W["cls"] = m.cls_token.detach().to(device=device, dtype=dtype).reshape(-1).contiguous()
         W["pos"] = m.pos_embed.detach().to(device=device, dtype=dtype).reshape(-1, desc["C"]).contiguous()

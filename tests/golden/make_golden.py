@@ -226,6 +226,7 @@ def main():
         ("deit3_fp32", "deit3_base_patch16_224", README_SCHEDULE, 2, 3, 0.04, 0.02, torch.float32),
         ("large384_fp32", "vit_large_patch16_384", AGGRESSIVE_L384, 1, 4, 0.03, 0.02, torch.float32),
         ("microd80_fp32", "vit_micro_d80_patch16_64", MICRO_SCHEDULE, 3, 5, 0.08, 0.02, torch.float32),
+        ("microp14_fp32", "vit_micro_patch14_56", MICRO_SCHEDULE, 3, 6, 0.08, 0.02, torch.float32),
     ]
     for c in cases:
         if only and c[0] not in only:

@@ -22,7 +22,7 @@ from rajni_amd import timm_shaped as ts
 from helpers import load_case, case_state_dict, case_images, pruned_blocks
 
 DEV = "cuda"
-CASES = ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32"]
+CASES = ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32", "microp14_fp32"]
 
 
 def build(meta):

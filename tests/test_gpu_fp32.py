@@ -101,19 +101,19 @@ def test_layernorm_and_patch_embed_f32():
     b = (0.1 * rng.standard_normal(768)).astype(np.float32)
     y = ops.layernorm(dev(x), dev(w), dev(b), 1e-6, out_dtype=torch.float32)
     close(host(y), orc.layer_norm(x.astype(np.float64), w, b, 1e-6), 3e-6, "layernorm f32")
-    S, P, Cc, B = 64, 16, 128, 3
-    img = rng.standard_normal((B, 3, S, S), dtype=np.float32)
-    wc = rng.standard_normal((Cc, 3, P, P), dtype=np.float32) * 0.05
-    bc = rng.standard_normal(Cc, dtype=np.float32) * 0.1
-    cls = rng.standard_normal(Cc, dtype=np.float32)
-    pos = rng.standard_normal((17, Cc), dtype=np.float32)
-    xx = ops.patch_embed(dev(img), ops.pack_weight(dev(wc), torch.float32), dev(bc), dev(cls), dev(pos), True, P, Cc, out_f32=True)
-    tok = orc.patch_embed(img.astype(np.float64), wc.astype(np.float64), bc.astype(np.float64))
-    want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok], axis=1) + pos[None]
-    close(host(xx), want, 3e-6, "patch embed f32")
+    for S, P, Cc, B in [(64, 16, 128, 3), (56, 14, 128, 3), (30, 10, 64, 2)]:   # fused loader / materialised columns
+        img = rng.standard_normal((B, 3, S, S), dtype=np.float32)
+        wc = rng.standard_normal((Cc, 3, P, P), dtype=np.float32) * 0.05
+        bc = rng.standard_normal(Cc, dtype=np.float32) * 0.1
+        cls = rng.standard_normal(Cc, dtype=np.float32)
+        pos = rng.standard_normal(((S // P) ** 2 + 1, Cc), dtype=np.float32)
+        xx = ops.patch_embed(dev(img), ops.pack_weight(dev(wc), torch.float32, k_multiple=64), dev(bc), dev(cls), dev(pos), True, P, Cc, out_f32=True)
+        tok = orc.patch_embed(img.astype(np.float64), wc.astype(np.float64), bc.astype(np.float64))
+        want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok], axis=1) + pos[None]
+        close(host(xx), want, 3e-6, f"patch embed f32 P={P}")
 
 
-@pytest.mark.parametrize("name", ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32"])
+@pytest.mark.parametrize("name", ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32", "microp14_fp32"])
 def test_forward_f32_equals_reference(name):
     """Free-running fp32 forward vs the reference's fp32 run: same keep_idx (bit exact wherever the
     reference's own boundary gap exceeds fp32 noise), same token_counts, logits within 1e-3."""

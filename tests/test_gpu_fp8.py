@@ -131,7 +131,7 @@ def _build(meta):
     return cfg, wrapped
 
 
-@pytest.mark.parametrize("name", ["micro_fp32", "base224_fp32", "deit3_fp32", "microd80_fp32"])
+@pytest.mark.parametrize("name", ["micro_fp32", "base224_fp32", "deit3_fp32", "microd80_fp32", "microp14_fp32"])
 def test_fp8_forward_vs_oracle_on_dequantised_weights(name):
     """Whole forward with fp8 block weights == the oracle (fp32 numpy restatement of the reference) run on the
     dequantised weights with the device's own selections injected: same 1e-2-of-logit-scale bar as bf16."""

@@ -316,7 +316,11 @@ def test_attention_online_softmax_spike(attn_mode):
 
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("S,P,Cc,B,has_cls", [(64, 16, 128, 3, True), (224, 16, 192, 2, True), (64, 16, 128, 2, False),
-                                              (32, 8, 64, 5, True)])
+                                              (32, 8, 64, 5, True),
+                                              # not a power of two / K not whole K steps: materialised columns
+                                              (56, 14, 128, 3, True), (224, 14, 320, 2, False), (70, 10, 64, 2, True),
+                                              (28, 7, 64, 9, True), (36, 4, 128, 2, True), (96, 32, 192, 2, True),
+                                              (60, 12, 64, 1, True)])
 def test_patch_embed(S, P, Cc, B, has_cls, out_f32, tiling):
     rng = np.random.default_rng(S + Cc)
     img = bf16_round_np(rng.standard_normal((B, 3, S, S), dtype=np.float32))
@@ -325,7 +329,7 @@ def test_patch_embed(S, P, Cc, B, has_cls, out_f32, tiling):
     cls = bf16_round_np(rng.standard_normal(Cc, dtype=np.float32))
     npatch = (S // P) ** 2
     pos = bf16_round_np(rng.standard_normal((npatch + int(has_cls), Cc), dtype=np.float32))
-    x = ops.patch_embed(dev_bf16(img), ops.pack_weight(dev_bf16(w)), torch.from_numpy(b).to(DEV), dev_bf16(cls),
+    x = ops.patch_embed(dev_bf16(img), ops.pack_weight(dev_bf16(w), k_multiple=64), torch.from_numpy(b).to(DEV), dev_bf16(cls),
                         dev_bf16(pos), has_cls, P, Cc, out_f32=out_f32)
     tok = orc.patch_embed(img.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
     if has_cls:

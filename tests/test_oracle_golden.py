@@ -9,7 +9,7 @@ import pytest
 from oracle import rajni_oracle as orc
 from helpers import GOLDEN, load_case, case_state_dict, case_images, pruned_blocks
 
-FP32_CASES = ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32"]
+FP32_CASES = ["micro_fp32", "tiny224_fp32", "base224_fp32", "deit3_fp32", "large384_fp32", "microd80_fp32", "microp14_fp32"]
 
 
 def test_importance_cases():
