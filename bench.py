@@ -183,6 +183,9 @@ def main():
     fl_img, _ = flops_per_image(cfg, schedule)
     value = world * B * args.steps / elapsed
     # dominant kernel = the GEMM instantiation with the most time
+    # BASELINE.json's metric is quoted on this workload; other --model/--schedule/--batch runs are labelled as such
+    headline_workload = (args.model == "vit_base_patch16_224" and not args.schedule and args.batch == 256
+                         and args.weight_format == "model")
     roofline = None
     if prof:
         name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
@@ -193,8 +196,9 @@ def main():
         # command and committed under profiles/ - null when that file does not cover the kernel
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_pmc.json")) as f:
-                traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
+            if headline_workload:      # the PMC profile was taken over the default command only
+                with open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_pmc.json")) as f:
+                    traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         # every GEMM class here is priced against the MFMA roof except the attention projection (K <= N),
@@ -215,7 +219,9 @@ def main():
                                      "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)}
                                  for k, v in prof.items()}}
 
-    out = {"metric": "images/sec ViT-B/16@224 with README schedule", "value": round(value, 1), "unit": "images/sec",
+    out = {"metric": "images/sec ViT-B/16@224 with README schedule" if headline_workload
+                     else f"images/sec {args.model} (not the BASELINE workload: see config.workload)",
+           "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"{args.model} bf16{' activations, fp8 e4m3 block weights' if args.weight_format == 'fp8' else ''}, "

@@ -50,18 +50,21 @@ def quantize_rows_fp8(w: torch.Tensor):
     return q, scale
 
 
-def pack_weight_fp8(w: torch.Tensor, model_dtype=torch.bfloat16, device=None):
+def pack_weight_fp8(w: torch.Tensor, model_dtype=torch.bfloat16, device=None, k_multiple: int = 1):
     """[N, K...] Linear weight -> (uint8 [ceil256(N), K] of e4m3 bytes with zero padded rows, fp32 scale [N]).
-    The weight is first rounded to `model_dtype` (what the reference model would hold), then quantised."""
+    The weight is first rounded to `model_dtype` (what the reference model would hold), then quantised.
+    `k_multiple` zero-pads the columns (e4m3 0x00 = +0) like pack_weight."""
     n = w.shape[0]
     w2 = w.detach().reshape(n, -1).to(model_dtype)
-    if w2.shape[1] % 16 != 0:
-        raise ValueError("fp8 weights need the input dimension to be a multiple of 16")
+    k = w2.shape[1]
+    kpad = (k + k_multiple - 1) // k_multiple * k_multiple
+    if kpad % 16 != 0:
+        raise ValueError("fp8 weights need the (padded) input dimension to be a multiple of 16")
     q, scale = quantize_rows_fp8(w2)
     dev = device if device is not None else w.device
     npad = (n + 255) // 256 * 256
-    out = torch.zeros((npad, w2.shape[1]), dtype=torch.uint8, device=dev)
-    out[:n].copy_(q.view(torch.uint8))
+    out = torch.zeros((npad, kpad), dtype=torch.uint8, device=dev)
+    out[:n, :k].copy_(q.view(torch.uint8))
     return out, scale.to(dev).contiguous()
 
 

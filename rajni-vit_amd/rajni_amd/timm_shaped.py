@@ -70,6 +70,8 @@ CONFIGS: Dict[str, ViTConfig] = {
     "vit_large_patch16_384": ViTConfig(img_size=384, embed_dim=1024, depth=24, num_heads=16),
     "deit3_base_patch16_224": ViTConfig(embed_dim=768, depth=12, num_heads=12,
                                         layer_scale=1e-6, no_embed_class=True),
+    # head dim 80, patch 14: the general attention / importance kernels and the materialised patch columns
+    "vit_huge_patch14_224": ViTConfig(patch_size=14, embed_dim=1280, depth=32, num_heads=16),
     # tiny head_dim-64 model for fast parity tests (not a timm name)
     "vit_micro_patch16_64": ViTConfig(img_size=64, embed_dim=128, depth=4, num_heads=2,
                                       num_classes=10),

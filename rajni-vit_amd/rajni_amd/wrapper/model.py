@@ -130,9 +130,15 @@ class RAJNIViTWrapper(nn.Module):
         if self._weights is None or self._weight_format != "fp8":
             raise RuntimeError("run a forward with set_weight_format('fp8') first")
         out = {}
+        hid = self._weights["desc"]["hidden"]
         for i, bw in enumerate(self._weights["blocks"]):
             for ours, theirs in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
-                out[f"blocks.{i}.{theirs}.weight"] = ops.dequantize_fp8(bw[ours + "_w"], bw[ours + "_s"])
+                w = ops.dequantize_fp8(bw[ours + "_w"], bw[ours + "_s"])
+                if ours == "fc1":
+                    w = w[:hid]               # rows / columns past the model's MLP width are zero padding
+                elif ours == "fc2":
+                    w = w[:, :hid]
+                out[f"blocks.{i}.{theirs}.weight"] = w
         return out
 
     def set_last_block_cls_only(self, on: bool = True):
@@ -176,6 +182,7 @@ class RAJNIViTWrapper(nn.Module):
         desc = dict(C=Cdim, H=heads, D=Cdim // heads, depth=len(self.blocks), hidden=blk0.mlp.fc1.out_features,
                     num_classes=m.head.out_features, patch=pe.kernel_size[0], in_chans=pe.in_channels,
                     ln_eps=float(blk0.norm1.eps), scale=float(blk0.attn.scale))
+        desc["hidden_pad"] = (desc["hidden"] + 63) // 64 * 64
         for i, blk in enumerate(self.blocks):
             for ln in (blk.norm1, blk.norm2):
                 if not isinstance(ln, nn.LayerNorm) or ln.weight is None or float(ln.eps) != desc["ln_eps"]:
@@ -243,13 +250,26 @@ class RAJNIViTWrapper(nn.Module):
                 if dp is not None and not isinstance(dp, nn.Identity) and self.training:
                     raise NotImplementedError("drop_path in training mode: this is the inference path")
             (qkv_w, qkv_s), (proj_w, proj_s) = pq(a.qkv.weight), pq(a.proj.weight)
-            (fc1_w, fc1_s), (fc2_w, fc2_s) = pq(blk.mlp.fc1.weight), pq(blk.mlp.fc2.weight)
+            # An MLP width that is not whole 64-wide K steps (so400m: 4304) is zero-padded: fc1 gets zero rows (it
+            # has them anyway, up to the next 256) with zero bias, GELU(0) = 0 lands in the padding columns of the
+            # hidden buffer, and fc2's zero-padded input columns ignore them - exact, no kernel involved.
+            hid, hpad = desc["hidden"], desc["hidden_pad"]
+            (fc1_w, fc1_s) = pq(blk.mlp.fc1.weight)
+            if fp8:
+                fc2_w, fc2_s = ops.pack_weight_fp8(blk.mlp.fc2.weight, dtype, device, k_multiple=64)
+                if hpad != hid:
+                    fc1_s = torch.cat([fc1_s, torch.ones(hpad - hid, dtype=fc1_s.dtype, device=fc1_s.device)])
+            else:
+                fc2_w, fc2_s = ops.pack_weight(blk.mlp.fc2.weight, dtype, device, k_multiple=64), None
+            fc1_b = pv(blk.mlp.fc1.bias) if blk.mlp.fc1.bias is not None else zeros(hid)
+            if hpad != hid:
+                fc1_b = torch.cat([fc1_b, zeros(hpad - hid)])
             blocks.append(dict(
                 norm1_w=pv(blk.norm1.weight), norm1_b=pv(blk.norm1.bias),
                 qkv_w=qkv_w, qkv_s=qkv_s, qkv_b=pv(a.qkv.bias) if a.qkv.bias is not None else zeros(3 * desc["C"]),
                 proj_w=proj_w, proj_s=proj_s, proj_b=pv(a.proj.bias) if a.proj.bias is not None else zeros(desc["C"]),
                 ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
-                fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=pv(blk.mlp.fc1.bias),
+                fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=fc1_b,
                 fc2_w=fc2_w, fc2_s=fc2_s, fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
@@ -310,7 +330,7 @@ class RAJNIViTWrapper(nn.Module):
         plan = nat.VitPlan()
         plan.dtype = nat.dtype_code(dtype)
         plan.B, plan.in_chans, plan.img_size, plan.patch_size = B, d["in_chans"], S, d["patch"]
-        plan.C, plan.H, plan.D, plan.depth, plan.hidden = d["C"], d["H"], d["D"], d["depth"], d["hidden"]
+        plan.C, plan.H, plan.D, plan.depth, plan.hidden = d["C"], d["H"], d["D"], d["depth"], d["hidden_pad"]
         plan.num_classes, plan.ln_eps, plan.attn_scale = d["num_classes"], d["ln_eps"], d["scale"]
         plan.pos_has_cls = pos_has_cls
         plan.patch_w, plan.patch_b = W["patch_w"].data_ptr(), W["patch_b"].data_ptr()

@@ -144,3 +144,32 @@ def test_forward_any_head_dim_vs_oracle(heads, D, dtype):
     wrapped.set_last_block_cls_only(True)
     again = wrapped(torch.from_numpy(imgs).to(DEV).to(dtype)).float().cpu().numpy()
     close(again, logits, 8e-3 if dtype == torch.bfloat16 else 1e-5, "cls-only last block")
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp32", "fp8"])
+@pytest.mark.parametrize("hidden", [336, 200, 1080])
+def test_forward_mlp_width_not_whole_k_steps(hidden, fmt):
+    """An MLP width that is not a multiple of 64 (timm so400m: 4304): the wrapper zero-pads fc1's rows / bias and
+    fc2's columns to whole K steps at pack time; the logits are those of the unpadded model (oracle)."""
+    C, heads = 128, 2
+    cfg = ts.ViTConfig(img_size=64, embed_dim=C, depth=3, num_heads=heads, num_classes=10, mlp_ratio=hidden / C)
+    assert cfg.hidden_dim == hidden and hidden % 64 != 0
+    sched = {1: {"keep_ratio": 0.7, "update": True}}
+    model = ts.create_model(cfg, seed=hidden, std=0.08, bias_std=0.02, round_bf16=True)
+    dtype = torch.float32 if fmt == "fp32" else torch.bfloat16
+    rng = np.random.default_rng(hidden)
+    imgs = bf16_round_np(rng.standard_normal((2, 3, 64, 64), dtype=np.float32))
+    wrapped = rajni_amd.RAJNIViTWrapper(model, sched).to(DEV).to(dtype).eval().trace_scores(True)
+    if fmt == "fp8":
+        wrapped.set_weight_format("fp8")
+    logits = wrapped(torch.from_numpy(imgs).to(DEV).to(dtype)).float().cpu().numpy()
+    sd = ts.state_dict_numpy(model)
+    if fmt == "fp8":
+        for k, v in wrapped.dequantized_state_dict().items():
+            assert sd[k].shape == tuple(v.shape), k
+            sd[k] = v.cpu().numpy()
+    forced = {i: d["keep_idx"].cpu().numpy() for i, d in wrapped.get_last_trace().items()}
+    want, stats = orc.vit_forward(sd, imgs, sched, depth=cfg.depth, num_heads=heads, ln_eps=cfg.ln_eps,
+                                  forced_keep=forced, dtype=np.float32)
+    assert wrapped.get_last_stats() == stats
+    close(logits, want, 1e-3 if fmt == "fp32" else 1.5e-2, f"forward hidden={hidden} {fmt}")
