@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(256) attn_f32_d64(const AttnArgsF32 a) {
 // Any head dim D with D % 8 == 0, D <= 128 (ViT-H 80, ViT-g 88, EVA/SigLIP 72...128, small heads 32/48): the
 // general path beside the tuned D = 64 kernels above.  Same orientation - S^T = K Q^T, O^T += V^T P^T, the
 // exponentiated S^T accumulator is the next MFMA's B operand - on v_mfma_f32_16x16x16_bf16, whose contraction
-// step of 16 fits every such D after zero-padding to DP = 16 * ceil(D / 16) in LDS.  Workgroup = 4 waves x 16
+// step of 16 fits every such D after zero-padding to DP = 16 * ceil(D / 16) in LDS.  Workgroup = 4 waves x 32
 // query rows of one (image, head); keys in chunks of 64: K row-major, V transposed, both padded to
 // conflict-free strides; online softmax per chunk in fp32 (per-query state is per-lane, replicated over
 // the four lane groups).  Operand layouts (lane l: r = l % 16, g = l / 16, j = 0..3):
@@ -649,9 +649,10 @@ __global__ void __launch_bounds__(256) attn_f32_d64(const AttnArgsF32 a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int AG_KSTRIDE = 136;   // bf16 per K row in LDS (128 + 8): 16 rows x 2 lane groups hit 64 distinct banks
 constexpr int AG_VSTRIDE = 68;    // bf16 per V^T row (64 keys + 4)
+constexpr int AG_QROWS = 128;     // query rows per workgroup: 4 waves x 2 blocks of 16
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-__global__ void __launch_bounds__(256) attn_bf16_dgen(const AttnArgs a, int D) {
+__global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D) {
   __shared__ __attribute__((aligned(16))) bf16_t sk[64 * AG_KSTRIDE];
   __shared__ __attribute__((aligned(16))) bf16_t svt[128 * AG_VSTRIDE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -662,104 +663,162 @@ __global__ void __launch_bounds__(256) attn_bf16_dgen(const AttnArgs a, int D) {
   const bf16_t* img = a.qkv + (long)b * a.n_src * C3 + head * D;
   const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
 
-  int q = blockIdx.x * 64 + wave * 16 + r;
-  const bool valid = q < np;
-  if (!valid) q = np - 1;
-  s16x4_t qf[8];                                 // B operand of S^T: Q[q][16 kd + 4g + j]
-  {
-    const int srow = idx ? idx[q] : q;
+  // a wave owns two blocks of 16 query rows: every K / V^T fragment read from LDS feeds two MFMAs
+  int q[2];
+  bool valid[2];
+  s16x4_t qf[2][8];                              // B operand of S^T: Q[q][16 kd + 4g + j]
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    q[u] = blockIdx.x * AG_QROWS + wave * 32 + u * 16 + r;
+    valid[u] = q[u] < np;
+    if (!valid[u]) q[u] = np - 1;
+    const int srow = idx ? idx[q[u]] : q[u];
     const bf16_t* qp = img + (long)srow * C3;
 #pragma unroll
     for (int kd = 0; kd < 8; ++kd) {
-      qf[kd] = s16x4_t{0, 0, 0, 0};
+      qf[u][kd] = s16x4_t{0, 0, 0, 0};
       const int d0 = 16 * kd + 4 * g;
-      if (kd < ND && d0 < D) qf[kd] = *reinterpret_cast<const s16x4_t*>(qp + d0);   // D % 4 == 0: whole or nothing
+      if (kd < ND && d0 < D) qf[u][kd] = *reinterpret_cast<const s16x4_t*>(qp + d0);   // D % 4 == 0: whole or nothing
     }
   }
-  f32x4 o[8];
+  f32x4 o[2][8];
 #pragma unroll
-  for (int db = 0; db < 8; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_part = 0.f;
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[u][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
   const int chunks8 = 2 * ND;                   // 8-element pieces per staged row (covering DP)
+
+  // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before chunk c is
+  // computed (up to 4 K pieces + 4 V pieces of 16 bytes per thread), so their latency hides under the MFMAs.
+  uint4 kreg[4], vreg[4];
+  const int n_kitems = 64 * chunks8, n_vitems = 16 * chunks8;   // <= 1024 / <= 256
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int item = tid + 256 * i;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (item < n_kitems) {
+        const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
+        const int t = c0 + row;
+        if (t < np && d0 < D) {                 // D % 8 == 0: a piece is whole or padding
+          const int srow = idx ? idx[t] : t;
+          kreg[i] = *reinterpret_cast<const uint4*>(img + (long)srow * C3 + C + d0);
+        }
+      }
+    }
+    if (tid < n_vitems) {                       // 8 dims of FOUR consecutive keys
+      const int r4 = tid / chunks8, d0 = (tid - r4 * chunks8) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = c0 + 4 * r4 + i;
+        vreg[i] = make_uint4(0, 0, 0, 0);
+        if (t < np && d0 < D) {
+          const int srow = idx ? idx[t] : t;
+          vreg[i] = *reinterpret_cast<const uint4*>(img + (long)srow * C3 + 2 * C + d0);
+        }
+      }
+    }
+  };
+  fetch(0);
 
   for (int c0 = 0; c0 < np; c0 += 64) {
     __syncthreads();                            // everyone is done reading the previous chunk
-    for (int item = tid; item < 64 * chunks8; item += 256) {
-      const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
-      const int t = c0 + row;
-      uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
-      if (t < np && d0 < D) {                   // D % 8 == 0: a piece is whole or padding
-        const int srow = idx ? idx[t] : t;
-        const bf16_t* rp = img + (long)srow * C3 + d0;
-        kq = *reinterpret_cast<const uint4*>(rp + C);
-        vq = *reinterpret_cast<const uint4*>(rp + 2 * C);
-      }
-      *reinterpret_cast<uint4*>(sk + row * AG_KSTRIDE + d0) = kq;
-      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vq);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) svt[(d0 + j) * AG_VSTRIDE + row] = ve[j];
+    for (int i = 0; i < 4; ++i) {
+      const int item = tid + 256 * i;
+      if (item < n_kitems) {
+        const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
+        *reinterpret_cast<uint4*>(sk + row * AG_KSTRIDE + d0) = kreg[i];
+      }
+    }
+    if (tid < n_vitems) {                       // V transposed: eight 8-byte stores of 4 keys each
+      const int r4 = tid / chunks8, d0 = (tid - r4 * chunks8) * 8;
+      const unsigned w[4][4] = {{vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w}, {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w},
+                                {vreg[2].x, vreg[2].y, vreg[2].z, vreg[2].w}, {vreg[3].x, vreg[3].y, vreg[3].z, vreg[3].w}};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {             // element j of key i = half (j & 1) of dword j >> 1
+        unsigned e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xFFFFu);
+        *reinterpret_cast<uint2*>(svt + (d0 + j) * AG_VSTRIDE + 4 * r4) = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      }
     }
     __syncthreads();
+    if (c0 + 64 < np) fetch(c0 + 64);
 
-    f32x4 st[4];
-    float mloc = -INFINITY;
+    f32x4 st[2][4];
+    float mloc[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[0][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[1][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kd = 0; kd < 8; ++kd)
         if (kd < ND) {
           const s16x4_t ka = *reinterpret_cast<const s16x4_t*>(sk + (16 * kb + r) * AG_KSTRIDE + 16 * kd + 4 * g);
-          st[kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[kd], st[kb], 0, 0, 0);
+          st[0][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[0][kd], st[0][kb], 0, 0, 0);
+          st[1][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[1][kd], st[1][kb], 0, 0, 0);
         }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = c0 + 16 * kb + 4 * g + j;
-        const float v = key < np ? st[kb][j] * a.c : -INFINITY;   // log2 domain
-        st[kb][j] = v;
-        mloc = fmaxf(mloc, v);
-      }
-    }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);       // finite: every chunk holds at least one real key
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    s16x4_t pf[4];
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      float pv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pv[j] = __builtin_amdgcn_exp2f(st[kb][j] - m_new);
-        psum += pv[j];
-      }
-      const unsigned lo = pack2bf(pv[0], pv[1]), hi = pack2bf(pv[2], pv[3]);
-      pf[kb] = __builtin_bit_cast(s16x4_t, make_uint2(lo, hi));
+        for (int j = 0; j < 4; ++j) {
+          const int key = c0 + 16 * kb + 4 * g + j;
+          const float v = key < np ? st[u][kb][j] * a.c : -INFINITY;   // log2 domain
+          st[u][kb][j] = v;
+          mloc[u] = fmaxf(mloc[u], v);
+        }
     }
-    l_part = fmaf(l_part, alpha, psum);
+    float alpha[2];
+    s16x4_t pf[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float ml = fmaxf(mloc[u], __shfl_xor(mloc[u], 16, 64));
+      ml = fmaxf(ml, __shfl_xor(ml, 32, 64));
+      const float m_new = fmaxf(m_run[u], ml);      // finite: every chunk holds at least one real key
+      alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+      m_run[u] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        float pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pv[j] = __builtin_amdgcn_exp2f(st[u][kb][j] - m_new);
+          psum += pv[j];
+        }
+        pf[u][kb] = __builtin_bit_cast(s16x4_t, make_uint2(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])));
+      }
+      l_part[u] = fmaf(l_part[u], alpha[u], psum);
+    }
 #pragma unroll
     for (int db = 0; db < 8; ++db)
       if (db < ND) {
-        o[db] *= alpha;
+        o[0][db] *= alpha[0];
+        o[1][db] *= alpha[1];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const s16x4_t va = *reinterpret_cast<const s16x4_t*>(svt + (16 * db + r) * AG_VSTRIDE + 16 * kb + 4 * g);
-          o[db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[kb], o[db], 0, 0, 0);
+          o[0][db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[0][kb], o[0][db], 0, 0, 0);
+          o[1][db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[1][kb], o[1][db], 0, 0, 0);
         }
       }
   }
-  float l = l_part + __shfl_xor(l_part, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  if (valid) {
-    const float inv = 1.0f / l;
-    bf16_t* op = a.out + ((long)b * np + q) * C + head * D;
 #pragma unroll
-    for (int db = 0; db < 8; ++db) {
-      const int d0 = 16 * db + 4 * g;
-      if (db < ND && d0 < D)
-        *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[db][0] * inv, o[db][1] * inv), pack2bf(o[db][2] * inv, o[db][3] * inv));
+  for (int u = 0; u < 2; ++u) {
+    float l = l_part[u] + __shfl_xor(l_part[u], 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (valid[u]) {
+      const float inv = 1.0f / l;
+      bf16_t* op = a.out + ((long)b * np + q[u]) * C + head * D;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        const int d0 = 16 * db + 4 * g;
+        if (db < ND && d0 < D)
+          *reinterpret_cast<uint2*>(op + d0) =
+              make_uint2(pack2bf(o[u][db][0] * inv, o[u][db][1] * inv), pack2bf(o[u][db][2] * inv, o[u][db][3] * inv));
+      }
     }
   }
 }
@@ -962,7 +1021,7 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   ProfScope prof(KC_ATTENTION, s, flops, bytes);
   const int nsub = (np + 31) / 32;
   if (D != 64) {
-    hipLaunchKernelGGL(attn_bf16_dgen, dim3((np + 63) / 64, H, B), dim3(256), 0, s, a, D);
+    hipLaunchKernelGGL(attn_bf16_dgen, dim3((np + AG_QROWS - 1) / AG_QROWS, H, B), dim3(256), 0, s, a, D);
   } else if (nsub <= 8 && g_force_attn != 1) {
     int rc = RAJNI_OK;
     switch (nsub) {
