@@ -197,7 +197,7 @@ def main():
         traffic = None
         try:
             if headline_workload:      # the PMC profile was taken over the default command only
-                with open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic_pmc.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r01_m_hbm_traffic_pmc.json")) as f:
                     traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -211,7 +211,7 @@ def main():
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic,
-                    "traffic_source": "profiles/r01_k_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                    "traffic_source": "profiles/r01_m_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": rec["launches"],
                     "all_gemm": {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
@@ -233,7 +233,7 @@ def main():
            "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
            "roofline": roofline}
 
-    if world == 1:
+    if world == 1 and not args.no_torch_baseline:   # (side measurements are skipped together: profiling runs)
         # opt-in shortcut, NOT part of `value`: the last block computed for the CLS row only (the head reads
         # nothing else; same logits - tests/test_gpu_forward.py::test_cls_only_last_block_*).  `value` above is
         # the row-for-row forward, the reference's op graph.

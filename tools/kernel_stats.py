@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-kernel summary (CSV) of a rocprofv3 --kernel-trace run from its rocpd sqlite output:
+    rocprofv3 --kernel-trace --stats -d out -o run -- python3 bench.py ...
+    python tools/kernel_stats.py out/run_results.db > profiles/rNN_kernel_stats.csv"""
+import csv
+import re
+import sqlite3
+import sys
+
+cur = sqlite3.connect(sys.argv[1]).cursor()
+rows = cur.execute("select name, duration from kernels").fetchall()
+agg = {}
+for name, dur in rows:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
+    a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+total = sum(a[1] for a in agg.values())
+w = csv.writer(sys.stdout)
+w.writerow(["name", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"])
+for name, (n, t, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    w.writerow([name, n, round(t / 1e3, 1), round(t / n / 1e3, 2), round(lo / 1e3, 2), round(hi / 1e3, 2), round(100 * t / total, 2)])
