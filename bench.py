@@ -174,6 +174,17 @@ def main():
         elapsed = float(t.item())
     prof = nat.profile_collect()
     counts = wrapped.get_last_stats()["token_counts"]
+    # the HBM-bound part of the path (score -> top-k -> compact, the keep_idx gather fused into the attention
+    # loads, LayerNorm): HIP-event timing of a few extra forwards OUTSIDE the timed region
+    hbm_prof = {}
+    if world == 1:
+        nat.profile_reset()
+        nat.profile_enable((1 << 4) | (1 << 5) | (1 << 6))
+        for _ in range(5):
+            wrapped(images)
+        torch.cuda.synchronize(dev)
+        nat.profile_enable(0)
+        hbm_prof = nat.profile_collect()
 
     if rank != 0:
         if dist is not None:
@@ -219,6 +230,10 @@ def main():
                                      "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)}
                                  for k, v in prof.items()}}
 
+    hbm_kernels = {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
+                       "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0),
+                       "frac_of_hbm_peak": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                   for k, v in hbm_prof.items() if v["launches"]}
     out = {"metric": "images/sec ViT-B/16@224 with README schedule" if headline_workload
                      else f"images/sec {args.model} (not the BASELINE workload: see config.workload)",
            "value": round(value, 1), "unit": "images/sec",
@@ -233,6 +248,11 @@ def main():
            "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
            "roofline": roofline}
 
+    if hbm_kernels:
+        # algorithmic bytes: score+select reads the K and V thirds of qkv once ((2NC + C) x 2 B per image) and writes
+        # indices/scores; attention reads the kept q, k, v rows through keep_idx and writes the output (the
+        # reference's separate gather copies do not exist); LayerNorm reads the fp32 stream and writes bf16
+        out["hbm_kernels"] = hbm_kernels
     if world == 1 and not args.no_torch_baseline:   # (side measurements are skipped together: profiling runs)
         # opt-in shortcut, NOT part of `value`: the last block computed for the CLS row only (the head reads
         # nothing else; same logits - tests/test_gpu_forward.py::test_cls_only_last_block_*).  `value` above is

@@ -25,7 +25,13 @@ struct ScoreArgs {          // T = activation dtype (bf16_t or float)
   void* scores_out;         // T [B,N] or null
   int* keep_idx;            // [B,keep+1]
   void* next_scores;        // T [B,keep+1] or null
+  unsigned long long* stamps;   // diagnostic builds (-DRAJNI_SS_STAMPS): 16 x u64 s_memtime per workgroup, or null
 };
+#ifdef RAJNI_SS_STAMPS
+#define SS_STAMP(i) do { if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SS_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float rank_key(float s) { return (s != s) ? INFINITY : s; }
 
@@ -59,6 +65,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   float* misc = mean + D;              // [16]
   int* wcount = reinterpret_cast<int*>(misc + 16);  // [8]
 
+  SS_STAMP(0);
   if (COMPUTE) {
     const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * N * 3 * C;
     const int LP = D >> 3;             // lanes per 2*D-byte head row
@@ -126,6 +133,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       }
     }
     __syncthreads();
+    SS_STAMP(1);
 
     // ---- per-head softmax statistics over ALL N tokens (importance.py:20)
     for (int h = wave; h < H; h += SS_THREADS / 64) {
@@ -145,6 +153,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       acls[n] = s / (float)H;
     }
     __syncthreads();  // logits are dead: region becomes vbar
+    SS_STAMP(2);
 
     // ---- vbar[n][:] = mean_h v[n,h,:]   (importance.py:24)
     const float inv_h = 1.0f / (float)H;
@@ -168,6 +177,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       for (int j = 0; j < 8; ++j) dst[j] = acc[j] * inv_h;
     }
     __syncthreads();
+    SS_STAMP(3);
     // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
     {
       const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;   // threads past nparts * D idle
@@ -206,6 +216,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       if (sub == 0) sc[n] = sqrtf(ss);
     }
     __syncthreads();
+    SS_STAMP(4);
     // ---- mu, unbiased std + eps over tokens   (importance.py:28-29)
     if (wave == 0) {
       float s = 0.f;
@@ -240,6 +251,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     __syncthreads();
   }
 
+  SS_STAMP(5);
   if (a.keep <= 0) return;
 
   // ---- rank patch tokens 1..N-1, keep rank < keep, compact in ascending index order
@@ -285,6 +297,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     kout[0] = 0;
     if (nout) st1(nout, sc[0]);
   }
+  SS_STAMP(6);
 }
 
 size_t ss_lds_bytes(int N, int H, int D) {
@@ -307,6 +320,7 @@ int launch_score_select(const void* qkv, const void* scores_in, int B, int N, in
   ScoreArgs a{};
   a.N = N; a.keep = keep; a.eps = eps;
   a.scores_out = scores_out; a.keep_idx = keep_idx; a.next_scores = next_scores;
+  a.stamps = rajni_g_stamps;
   size_t lds;
   if (qkv != nullptr) {
     RAJNI_REQUIRE(D >= 8 && D <= 128 && D % 8 == 0, RAJNI_ERR_UNSUPPORTED,
