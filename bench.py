@@ -248,6 +248,27 @@ def main():
            "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
            "roofline": roofline}
 
+    if headline_workload and world == 1:
+        # "top-1 delta vs the reference wrapper": there are no trained weights or labels here, so what can be stated is
+        # agreement with the reference's own outputs on the committed fixture (same model dims and schedule, seeded
+        # weights, reference selections injected - tests/test_gpu_forward.py holds the same comparison to 1e-2)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import load_case, case_images, pruned_blocks
+            meta, data = load_case("base224_fp32")
+            fx = ts.create_model(ts.CONFIGS[meta["cfg_name"]], seed=meta["seed"], std=meta["std"],
+                                 bias_std=meta["bias_std"], round_bf16=True)
+            fw = rajni_amd.RAJNIViTWrapper(fx, meta["schedule"]).to(dev).to(torch.bfloat16).eval()
+            fw.force_keep_idx({i: torch.from_numpy(data[f"blk{i}.keep_idx"]).to(dev) for i in pruned_blocks(meta)})
+            got = fw(torch.from_numpy(case_images(meta, data)).to(dev)).float().cpu().numpy()
+            ref = data["logits"]
+            out["reference_agreement"] = {
+                "fixture": "tests/golden/base224_fp32 (reference fp32 CPU run, ViT-B/16 dims, README schedule)",
+                "images": int(ref.shape[0]), "top1_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
+                "max_abs_dlogit_over_logit_scale": round(float(abs(got - ref).max() / abs(ref).max()), 5),
+                "token_counts_equal": fw.get_last_stats()["token_counts"] == data["token_counts"].tolist()}
+        except Exception as e:   # the bench line must not die on the side check
+            out["reference_agreement"] = {"error": repr(e)[:200]}
     if hbm_kernels:
         # algorithmic bytes: score+select reads the K and V thirds of qkv once ((2NC + C) x 2 B per image) and writes
         # indices/scores; attention reads the kept q, k, v rows through keep_idx and writes the output (the
