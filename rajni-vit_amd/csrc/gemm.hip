@@ -296,6 +296,26 @@ __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int
 // many loads are in flight and how much of their latency hides under MFMAs.  Measured on proj
 // (tools/proj_probe.py): 155 us -> 135 us with all loads of the tile issued before the first store,
 // -> (see profiles) with the loads issued one K step before the epilogue.
+// fp32 residual stream accesses of the interior-tile fast path: read once, written once, next touched by a
+// LayerNorm launch - RAJNI_GEMM_EPI_NT bit 0 = non-temporal stores, bit 1 = non-temporal loads (experiment)
+#ifndef RAJNI_GEMM_EPI_NT
+#define RAJNI_GEMM_EPI_NT 0
+#endif
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_stream(const float4* p) {
+  if constexpr ((RAJNI_GEMM_EPI_NT & 2) != 0) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *p;
+  }
+}
+__device__ __forceinline__ void stg_stream(float4* p, const float4& v) {
+  if constexpr ((RAJNI_GEMM_EPI_NT & 1) != 0)
+    __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+  else
+    *p = v;
+}
 template <int MI>
 struct ResidPrefetch {
   float4 r[MI][4];
@@ -315,7 +335,7 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
         if (p.ridx != nullptr) rrow = (long)(m / p.r_np) * p.r_nsrc + p.ridx[m];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          pre.r[mi][ni] = *reinterpret_cast<const float4*>(R + rrow * p.ldr + n0w + 16 * ni + 4 * g);
+          pre.r[mi][ni] = ldg_stream(reinterpret_cast<const float4*>(R + rrow * p.ldr + n0w + 16 * ni + 4 * g));
       }
       pre.valid = true;
     }
@@ -410,7 +430,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           o.y = fmaf(gam[4 * ni + 1], acc[ni][mi][1] + bias[4 * ni + 1], pre.r[mi][ni].y);
           o.z = fmaf(gam[4 * ni + 2], acc[ni][mi][2] + bias[4 * ni + 2], pre.r[mi][ni].z);
           o.w = fmaf(gam[4 * ni + 3], acc[ni][mi][3] + bias[4 * ni + 3], pre.r[mi][ni].w);
-          *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g) = o;
+          stg_stream(reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g), o);
         }
       return;
     }
