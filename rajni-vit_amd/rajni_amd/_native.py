@@ -91,6 +91,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+ABI_VERSION = 4     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
 _lib: Optional[C.CDLL] = None
 
 
@@ -108,6 +109,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.rajni_abi_version() != ABI_VERSION:   # struct layouts below would not match: refuse, do not guess
+        raise NativeError(f"{path} has ABI version {lib.rajni_abi_version()}, this package binds version {ABI_VERSION}: "
+                          "rebuild it with `python rajni-vit_amd/build.py --force`")
     _lib = lib
     return lib
 
