@@ -260,21 +260,29 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   int* kout = a.keep_idx + (long)b * (keep + 1);
   T* nout = a.next_scores ? reinterpret_cast<T*>(a.next_scores) + (long)b * (keep + 1) : nullptr;
   int running = 0;
-  for (int base_i = 1; base_i < N; base_i += SS_THREADS) {
-    const int i = base_i + tid;
+  // tpt = 1, 2, 4 or 8 lanes share a token's rank count (each a slice of the j range, summed by shuffles): with
+  // 197 tokens one lane per token left 60 % of the workgroup idle through a 196-step loop
+  const int tpt = (N - 1) * 8 <= SS_THREADS ? 8 : (N - 1) * 4 <= SS_THREADS ? 4 : (N - 1) * 2 <= SS_THREADS ? 2 : 1;
+  const int per_iter = SS_THREADS / tpt, sl = tid & (tpt - 1);
+  const int slice = (N - 1 + tpt - 1) / tpt;
+  for (int base_i = 1; base_i < N; base_i += per_iter) {
+    const int i = base_i + tid / tpt;
     const bool valid = i < N;
-    bool kept = false;
     float si = 0.f;
+    int rank = 0;
     if (valid) {
       si = sc[i];
       const float ki = rank_key(si);
-      int rank = 0;
-      for (int j = 1; j < N; ++j) {
+      const int j0 = 1 + sl * slice, j1 = j0 + slice < N ? j0 + slice : N;
+      for (int j = j0; j < j1; ++j) {
         const float kj = rank_key(sc[j]);
         rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
       }
-      kept = rank < keep;
     }
+    if (tpt >= 2) rank += __shfl_xor(rank, 1, 64);
+    if (tpt >= 4) rank += __shfl_xor(rank, 2, 64);
+    if (tpt >= 8) rank += __shfl_xor(rank, 4, 64);
+    const bool kept = valid && sl == 0 && rank < keep;
     const unsigned long long bal = __ballot(kept);
     if (lane == 0) wcount[wave] = __popcll(bal);
     __syncthreads();
