@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int SS_THREADS = 512;
+#ifndef RAJNI_SS_KU
+#define RAJNI_SS_KU 8   // K-pass chunks in flight per lane
+#endif
 
 struct ScoreArgs {          // T = activation dtype (bf16_t or float)
   const void* qkv;          // T [B,N,3C] or null (select-only)
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
         region[h * N + n] = dot * inv_sqrt_d;
       }
     } else {
-      constexpr int U = 8;
+      constexpr int U = RAJNI_SS_KU;
       const int CP = C >> 3;
       const int dn = SS_THREADS / CP, dc = SS_THREADS - dn * CP;   // item index += SS_THREADS
       int n = tid / CP, c = tid - n * CP;
