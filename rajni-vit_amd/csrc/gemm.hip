@@ -565,6 +565,42 @@ __device__ __forceinline__ void sched_half() {
     sched_half<G + 1, MI, DMA, PIECES, NI>();
   }
 }
+// Issue patterns of a half step.  0: MI groups of {NI MFMAs, 1-2 fragment reads, DMA pieces} (sched_half, the
+// default for every wave).  Experiment RAJNI_GEMM_PINGPONG: the two waves that share a SIMD (w and w + 4) get
+// DIFFERENT patterns so that one streams its MFMAs while the other issues its LDS reads and DMA - pattern 1: all
+// reads and DMA first, then the MFMAs; pattern 2: RAJNI_GEMM_PP_SPLIT MFMA groups, the reads and DMA, the rest.
+#ifndef RAJNI_GEMM_PINGPONG
+#define RAJNI_GEMM_PINGPONG 0
+#endif
+#ifndef RAJNI_GEMM_PP_SPLIT
+#define RAJNI_GEMM_PP_SPLIT 5
+#endif
+// MFMA groups [G0, G1) with their DMA pieces (no fragment reads)
+template <int G, int G1, int MI, bool DMA, int PIECES, int NI>
+__device__ __forceinline__ void sched_mfma_dma() {
+  if constexpr (G < G1) {
+    __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+    if constexpr (DMA) {
+      constexpr int nd = dma_first(G + 1, PIECES, MI) - dma_first(G, PIECES, MI);
+      if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
+    }
+    sched_mfma_dma<G + 1, G1, MI, DMA, PIECES, NI>();
+  }
+}
+template <int PAT, int MI, bool DMA, int PIECES, int NI>
+__device__ __forceinline__ void sched_pattern() {
+  if constexpr (PAT == 0) {
+    sched_half<0, MI, DMA, PIECES, NI>();
+  } else if constexpr (PAT == 1) {
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    sched_mfma_dma<0, MI, MI, DMA, PIECES, NI>();
+  } else {
+    constexpr int split = RAJNI_GEMM_PP_SPLIT < MI ? RAJNI_GEMM_PP_SPLIT : MI - 1;
+    sched_mfma_dma<0, split, MI, DMA, PIECES, NI>();
+    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+    sched_mfma_dma<split, MI, MI, DMA, PIECES, NI>();
+  }
+}
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
@@ -699,9 +735,10 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
 
   // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
   // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage dst
-  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], WFrag (&wc)[NI], bf16x8 (&xn)[MI], WFrag (&wn_)[NI],
+  auto half = [&](auto dma_c, auto pat_c, bf16x8 (&xc)[MI], WFrag (&wc)[NI], bf16x8 (&xn)[MI], WFrag (&wn_)[NI],
                   int rst, int rks, int dkt, int dst) {
     constexpr bool DMA = decltype(dma_c)::value;
+    constexpr int PAT = decltype(pat_c)::value;
     const char* sb = smem + rst * C::STAGE_BYTES;
     char* dx = smem + dst * C::STAGE_BYTES;
     const int k0 = dkt * BK;
@@ -722,9 +759,13 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
         for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
       }
     }
-    sched_half<0, MI, DMA, C::PIECES, NI>();
+    sched_pattern<PAT, MI, DMA, C::PIECES, NI>();
   };
   using T = std::true_type; using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using PA = std::integral_constant<int, RAJNI_GEMM_PINGPONG / 10>;    // waves 0..3   (RAJNI_GEMM_PINGPONG = 10 a + b)
+  using PB = std::integral_constant<int, RAJNI_GEMM_PINGPONG % 10>;    // waves 4..7
+  const bool second_group = wave >= WM * WN / 2;
 
   const int nk = p.K / BK;        // >= NS + 1 (host checked)
   int v = blockIdx.x;
@@ -758,6 +799,10 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
   constexpr int NSTORE = NSTORE_ALL < 48 ? NSTORE_ALL : 48;   // vmcnt is a 6-bit counter
   bool prev_full = false;          // the previous tile of this workgroup was interior
 
+  // the whole persistent loop per issue pattern: branching per half step instead would merge the two paths'
+  // accumulators after every half (measured: +70 VGPRs, 528 bytes of spills in the wide tiling)
+  auto run = [&](auto pat_c) {
+  using PAT = decltype(pat_c);
   while (true) {
 #ifdef RAJNI_GEMM_STAMPS
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -784,13 +829,13 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
       if (NH == 1 && kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
-      half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
+      half(F{}, PAT{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
       if (NSTORE > 0 && kt == 0 && prev_full) wait_step<WBASE + NSTORE>();
       else wait_step<WBASE>();
       __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
-      half(T{}, xb, wb, xa, wa, st1, 0, dkt, st);
+      half(T{}, PAT{}, xb, wb, xa, wa, st1, 0, dkt, st);
       st = st1;
     }
 #ifdef RAJNI_GEMM_STAMPS
@@ -817,6 +862,13 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
     if (!more) break;
     v = vn;
     tile = xcd_tile_of(v, p.total_tiles);
+  }
+  };
+  if constexpr (RAJNI_GEMM_PINGPONG != 0) {
+    if (second_group) run(PB{});
+    else run(PA{});
+  } else {
+    run(P0{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing (unused) DMA before LDS is released
 }
