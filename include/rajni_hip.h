@@ -123,6 +123,9 @@ void rajni_debug_force_gemm_tiling(int mode);
 /* test hook / tuning: W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the
  * plain column-fastest order; -k = blocks of k column tiles regardless of size */
 void rajni_debug_set_gemm_nblock_bytes(int bytes);
+/* tuning hook: second level of that order - super-blocks of `row_tiles` 256-row tiles, each walked (N block, row
+ * tile, column) before the next one starts (0 = one super-block spanning all rows, the default) */
+void rajni_debug_set_gemm_row_superblock(int row_tiles);
 /* tuning hook: 1 = launch the persistent GEMMs with the smallest grid that still finishes in the same number
  * of tile rounds (a multiple of 8 workgroups), 0 = one workgroup per CU (default) */
 void rajni_debug_set_gemm_balanced_grid(int on);

@@ -42,6 +42,7 @@ struct GemmParams {
   int M, N, K;
   int tiles_n, total_tiles;
   int nblk;                     // persistent tilings: column tiles per N block of the tile order (tile_mn)
+  int rblk;                     // ... row tiles per super-block (0: one super-block = all rows)
   // patch-embed A loader / epilogue
   int cin, S, log2ps, gw, npatch;
   const void* pos; int pos_off; // pos-embed rows, activation dtype
@@ -640,9 +641,20 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
   const int tiles_m = p.total_tiles / p.tiles_n;
   auto tile_mn = [&](int t, int& tm_, int& tn_) {
     if (p.nblk >= p.tiles_n) { tm_ = t / p.tiles_n; tn_ = t - tm_ * p.tiles_n; return; }
-    const int per = p.nblk * tiles_m, blk = t / per, r = t - blk * per;
+    // optional second level: super-blocks of rblk row tiles, inside each the (block, row tile, column) order -
+    // the X panels of a super-block are meant to stay in L2 across its N blocks instead of being streamed once
+    // per block over all of M
+    int row0 = 0, rows = tiles_m;
+    if (p.rblk > 0 && p.rblk < tiles_m) {
+      const int sbsz = p.rblk * p.tiles_n, sb = t / sbsz;
+      t -= sb * sbsz;
+      row0 = sb * p.rblk;
+      rows = tiles_m - row0 < p.rblk ? tiles_m - row0 : p.rblk;
+    }
+    const int per = p.nblk * rows, blk = t / per, r = t - blk * per;
     const int left = p.tiles_n - blk * p.nblk, nb = left < p.nblk ? left : p.nblk;
-    tm_ = r / nb; tn_ = blk * p.nblk + (r - tm_ * nb);
+    const int rr = r / nb;
+    tm_ = row0 + rr; tn_ = blk * p.nblk + (r - rr * nb);
   };
   XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : C::XP];   // fused im2col loader: one source per piece
   const char* xp[2];                                 // plain loader: even and odd pieces (16 rows apart each)
@@ -1179,6 +1191,7 @@ int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per
 int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stages), 4 wide 256x256x64, 5 mid 256x128x64 (tests)
 
 int g_nblk_bytes = RAJNI_GEMM_NBLK_BYTES;   // W bytes of one N block (0 = plain order, < 0 = forced block size: tuning)
+int g_rblk = 0;                              // row tiles per super-block of the tile order (0 = all rows; tuning hook)
 
 // column tiles per N block of the persistent tile order (see tile_mn).  Measured on the ViT-B shapes
 // (tools/nblk_bench.py): blocks of ~1.5 MiB of W help once every block spans at least two rounds of tiles
@@ -1244,6 +1257,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);   // fp8 W: same blocks as bf16 (measured)
+    p.rblk = g_rblk;
     const int grid = stream_grid(p.total_tiles);
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
 #ifdef RAJNI_GEMM_WIDE4
@@ -1258,6 +1272,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
       p.tiles_n = (p.N + 255) / 256;
       p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
       p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);
+      p.rblk = g_rblk;
       const int grid = stream_grid(p.total_tiles);
       hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 2, 8, 2, false, 2>), dim3(grid), dim3(256), C::LDS_BYTES, s, p);
     }
@@ -1267,6 +1282,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2);
+    p.rblk = g_rblk;
     const int grid = stream_grid(p.total_tiles);
     hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
   } else {
@@ -1283,6 +1299,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
+extern "C" void rajni_debug_set_gemm_row_superblock(int row_tiles) { g_rblk = row_tiles; }
 extern "C" void rajni_debug_set_gemm_balanced_grid(int on) { g_balance_grid = on; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }

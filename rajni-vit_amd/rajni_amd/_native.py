@@ -75,6 +75,7 @@ _SIGS = {
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "rajni_debug_force_gemm_tiling": (None, [c_int]),
     "rajni_debug_set_gemm_nblock_bytes": (None, [c_int]),
+    "rajni_debug_set_gemm_row_superblock": (None, [c_int]),
     "rajni_debug_set_gemm_balanced_grid": (None, [c_int]),
     "rajni_debug_force_attention": (None, [c_int]),
     "rajni_debug_set_gemm_stamps": (None, [c_void_p]),
