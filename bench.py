@@ -10,8 +10,9 @@ A "step" is one forward of one 256-image synthetic batch per GPU, images already
 One JSON line on stdout (rank 0).  Extra objects:
   roofline     - dominant kernel (the packed-token MFMA GEMM), timed live with HIP events on the
                  launch stream inside the timed region (rajni_profile_* hooks of the C ABI);
-  cpu_baseline - the numpy oracle (oracle/rajni_oracle.py, a port of the reference algorithm) timed
-                 on this box's host cores on a bounded sample of the same workload (rank 0, N=1).
+  cpu_baseline - the oracle's torch-CPU flavour (oracle/rajni_oracle_torch.py, a port of the reference algorithm
+                 on the ATen kernels the reference itself would run) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N=1).
 """
 import argparse
 import json
@@ -62,33 +63,31 @@ def usable_cores():
 
 
 def cpu_baseline(cfg, schedule, seconds_budget=20.0):
-    """Oracle (numpy port of the reference algorithm) on the host cores, fp32, same model/schedule."""
-    from oracle import rajni_oracle as orc
+    """The oracle's torch flavour (oracle/rajni_oracle_torch.py: the reference algorithm restated op for op on ATen CPU
+    kernels, pinned by the reference's fixtures) on this box's host cores, fp32, same model dims and schedule."""
+    from oracle import rajni_oracle_torch as ort
     from rajni_amd import timm_shaped as ts
     cores = usable_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
     try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=cores)
-    except Exception:
-        limiter = None
-    sd = ts.synth_state_dict(cfg, seed=0)
-    rng = np.random.default_rng(1234)
-    bsz = 8
-    imgs = rng.standard_normal((bsz, 3, cfg.img_size, cfg.img_size), dtype=np.float32)
-    run = lambda: orc.vit_forward(sd, imgs, schedule, depth=cfg.depth, num_heads=cfg.num_heads,
-                                  ln_eps=cfg.ln_eps, dtype=np.float32)
-    run()  # warm-up
-    n, t0 = 0, time.time()
-    while True:
-        run()
-        n += bsz
-        dt = time.time() - t0
-        if dt > seconds_budget or n >= 256:
-            break
-    del limiter
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in ts.synth_state_dict(cfg, seed=0).items()}
+        bsz = 16
+        imgs = torch.randn(bsz, 3, cfg.img_size, cfg.img_size, generator=torch.Generator().manual_seed(1234))
+        run = lambda: ort.vit_forward(sd, imgs, schedule, depth=cfg.depth, num_heads=cfg.num_heads, ln_eps=cfg.ln_eps)
+        run()  # warm-up
+        n, t0 = 0, time.time()
+        while True:
+            run()
+            n += bsz
+            dt = time.time() - t0
+            if dt > seconds_budget or n >= 4096:
+                break
+    finally:
+        torch.set_num_threads(prev)
     return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} synthetic 3x{cfg.img_size}x{cfg.img_size} images in batches of {bsz}, "
-                      f"same model dims and README schedule, fp32 numpy oracle, BLAS threads = {cores} "
+                      f"same model dims and schedule, fp32 torch-CPU oracle (ATen/oneDNN kernels), {cores} threads "
                       f"(usable cores of {os.cpu_count()} logical), {dt:.1f} s"}
 
 

@@ -15,6 +15,8 @@ the image); those parts follow timm's documented block semantics.
 
 Each function cites the reference file:line it restates (paths relative to /root/reference/rajni).
 All arithmetic is done in `dtype` (float64 by default: the oracle is the high-precision answer).
+`rajni_oracle_torch.py` is the same restatement on torch CPU ops (fp32), held to the same fixtures: it is what
+`bench.py` times as `cpu_baseline`, this module is what the parity tests check against.
 """
 from __future__ import annotations
 

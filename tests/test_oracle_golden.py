@@ -122,3 +122,46 @@ def test_keep_count_python_double_semantics():
     assert [orc.keep_count(r, n) + 1 for r, n in [(0.88, 197), (0.88, 173), (0.8, 152), (0.72, 121)]] == [173, 152, 121, 87]
     assert [orc.keep_count(r, n) + 1 for r, n in [(0.7, 577), (0.5, 404), (0.3, 202)]] == [404, 202, 61]
     assert orc.keep_count(0.0, 197) == 1 and orc.keep_count(1.0, 197) == 196
+
+
+# ---- the torch flavour of the oracle (what bench.py's cpu_baseline times) is held to the same fixtures ----------
+
+@pytest.mark.parametrize("name", FP32_CASES)
+def test_torch_oracle_matches_reference_fixture(name):
+    import torch
+    from oracle import rajni_oracle_torch as ort
+    meta, data = load_case(name)
+    cfg, sd = case_state_dict(meta)
+    sd_t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items()}
+    images = torch.from_numpy(case_images(meta, data).astype(np.float32))
+    # free running: token counts, scores, and selections wherever the reference's boundary gap is resolvable
+    logits, stats, trace = ort.vit_forward(sd_t, images, meta["schedule"], depth=cfg.depth, num_heads=cfg.num_heads,
+                                           ln_eps=cfg.ln_eps, return_trace=True)
+    assert stats["token_counts"] == data["token_counts"].tolist()
+    same = True
+    for i in pruned_blocks(meta):
+        np.testing.assert_allclose(trace[i]["scores"].numpy(), data[f"blk{i}.scores"], rtol=5e-4, atol=2e-7)
+        eq = np.array_equal(trace[i]["keep_idx"].numpy(), data[f"blk{i}.keep_idx"])
+        if meta["boundary_gap"][i] > 1e-6:
+            assert eq, (name, i)
+        same = same and eq
+        if not same:
+            break
+    # selection conditional: the reference's logits to fp32 round-off
+    forced = {i: data[f"blk{i}.keep_idx"] for i in pruned_blocks(meta)}
+    logits, _, trace = ort.vit_forward(sd_t, images, meta["schedule"], depth=cfg.depth, num_heads=cfg.num_heads,
+                                       ln_eps=cfg.ln_eps, forced_keep=forced, return_trace=True)
+    np.testing.assert_allclose(logits.numpy(), data["logits"], rtol=0, atol=2e-4)
+    for i in pruned_blocks(meta):
+        np.testing.assert_allclose(trace[i]["next_scores"].numpy(), data[f"blk{i}.next_scores"], rtol=5e-4, atol=2e-7)
+
+
+def test_torch_oracle_selection_rule_is_the_numpy_oracles():
+    import torch
+    from oracle import rajni_oracle_torch as ort
+    rng = np.random.default_rng(5)
+    s = np.round(rng.random((6, 50), dtype=np.float32), 1)          # many ties
+    s[2, 7] = np.nan
+    for keep in (1, 10, 49):
+        np.testing.assert_array_equal(ort.select_tokens(torch.from_numpy(s), keep).numpy(), orc.select_tokens(s, keep))
+    assert [ort.keep_count(r, n) for r, n in [(0.88, 197), (0.0, 197), (1.0, 197)]] == [orc.keep_count(r, n) for r, n in [(0.88, 197), (0.0, 197), (1.0, 197)]]
