@@ -362,3 +362,30 @@ def test_cls_only_last_block_is_skipped_when_the_last_block_prunes():
     a = w(x).float()
     b = w.set_last_block_cls_only(True)(x).float()
     assert torch.equal(a, b) and w.get_last_trace()[3]["keep_idx"].shape[1] == orc.keep_count(0.5, 17) + 1
+
+
+def test_forward_on_a_side_stream_and_changing_batch_shapes():
+    """The launches go to torch's CURRENT stream ("current stream only, no host sync inside forward"):
+    a forward enqueued on a side stream behind a slow producer must see the producer's data, and plans for
+    different batch / image shapes coexist (one native plan per shape)."""
+    meta, data = load_case("micro_fp32")
+    cfg, wrapped = build(meta)
+    images = torch.from_numpy(case_images(meta, data)).to(DEV).to(torch.bfloat16)
+    want = wrapped(images).float()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        junk = torch.randn(4096, 4096, device=DEV)
+        for _ in range(20):
+            junk = junk @ junk * 1e-3                 # keeps the side stream busy
+        staged = torch.empty_like(images)
+        staged.copy_(images)                          # produced ON the side stream, behind the matmuls
+        got = wrapped(staged).float()
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(got, want)
+    # other shapes in between, then the first shape again
+    for b in (1, 7, 4):
+        y = wrapped(images[:1].repeat(b, 1, 1, 1))
+        assert y.shape[0] == b
+        assert torch.equal(y.float(), want[:1].expand(b, -1))
+    assert torch.equal(wrapped(images).float(), want)
