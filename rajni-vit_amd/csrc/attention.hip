@@ -1,5 +1,6 @@
-// Fused softmax attention on the packed (kept) tokens, head dim 64  (reference
-// attention.py:42-54).  The keep_idx row gather is fused into the Q/K/V tile loads: nothing of the
+// Fused softmax attention on the packed (kept) tokens (reference attention.py:42-54):
+// tuned kernels for head dim 64 (this header describes them), a general MFMA kernel for every other
+// head dim % 8 == 0 up to 128 (attn_bf16_dgen), VALU kernels for fp32 models, and the CLS-row kernel.  The keep_idx row gather is fused into the Q/K/V tile loads: nothing of the
 // reference's gathered qkv copy or its [B,H,Np,Np] attention matrix ever reaches HBM.
 //
 // Work split: grid (ceil(Np/128), H, B); a workgroup = 4 waves, each wave owns 32 query rows.

@@ -8,11 +8,12 @@
 //     the LDS image is XOR-swizzled on the SOURCE address (LDS-DMA writes lane-linear) and the same
 //     involution is applied on the fragment reads -> conflict-free ds_read_b128;
 //   * v_mfma_f32_16x16x32_bf16 with W as the A operand and X as the B operand, so that a lane owns
-//     ONE output row m and - through a permutation of which W row feeds which fragment row -
-//     16 CONSECUTIVE output columns: epilogue loads/stores are 16-byte and row-contiguous, and
-//     per-row epilogue data (gathered residual row, patch->token row remap) is per-lane constant;
-//   * workgroup -> tile mapping walks N fastest inside an XCD-contiguous chunk, so the X panel of a
-//     tile row is fetched from HBM once per XCD and W stays L2-resident.
+//     ONE output row m and - through a permutation of which W row feeds which fragment row - a
+//     chosen set of output columns (MAP_SEC / MAP_NAT below): epilogue loads/stores are 16-byte and
+//     cover whole 64-byte sectors per row, and per-row epilogue data (gathered residual row,
+//     patch->token row remap) is per-lane constant;
+//   * workgroup -> tile mapping: every XCD gets a contiguous range of tile ids; ids run (N block of
+//     ~1.5 MiB of W, row tile, column in block), see tile_mn.
 //
 // Tilings (chosen per launch, see launch_gemm):
 //   wide  256 x 256 x 64, 8 waves, 2 LDS stages, persistent stream  - wide outputs (qkv, fc1)
@@ -20,7 +21,10 @@
 //   small 128 x 128 x 64, 4 waves, 2 stages, 2 workgroups per CU    - M < 1024 (head, tiny batches)
 //   f32   128 x 128 x 32(fp32) on v_mfma_f32_16x16x4_f32            - fp32 models
 // (Two further tilings, 256x128x32 and 128x128x32 with 3 stages of 64-byte rows, were built and
-//  measured in round 1 and removed: half-line DMA pieces made them slower than `small` on every shape.)
+//  measured in round 1 and removed: half-line DMA pieces made them slower than `small` on every shape.
+//  Build-time experiments kept behind macros, all off: RAJNI_GEMM_WIDE4 - the wide tile on four waves of
+//  128x128; RAJNI_GEMM_PINGPONG - different issue patterns for the two waves of a SIMD; RAJNI_GEMM_READ_FRONT,
+//  RAJNI_GEMM_DMA_FRONT, RAJNI_GEMM_EPI_NT, RAJNI_GEMM_X_AUX / W_AUX - DESIGN.md section 4 has the numbers.)
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
