@@ -1213,6 +1213,22 @@ inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes) {
   return (tiles_n + blocks - 1) / blocks;
 }
 
+// N = 768-class outputs with a long K (fc2): 256x128 tiles are the default, but when the tile count of the
+// 256x256 tiling happens to fill its rounds much better, it wins by 6-20 % (tools/fc2_grid_probe.py: 19 of 19
+// shapes of ViT-B / ViT-L / ViT-H at batch 64-512 picked right; fc2 at 152 tokens 226 -> 212 us, at batch 512
+// 660 -> 537 us).  Cost model: full rounds of 256 tiles plus a partial round whose tiles run faster the emptier
+// the chip is (board power cap: DESIGN.md section 4 (10)); one 256x256 round = 1.83 256x128 rounds.  Not used for
+// K <= N (proj): there the epilogue dominates a tile and the ratio is larger (measured: 4 misses of 11).
+inline double eff_rounds(long tiles) {
+  const long full = tiles / 256;
+  const double frac = (double)tiles / 256.0 - (double)full;
+  return (double)full + (frac > 0.0 ? 0.6 + 0.4 * frac : 0.0);
+}
+inline bool wide_wins_on_rounds(int M, int N) {
+  const long rows = (M + 255) / 256;
+  return 1.83 * eff_rounds(rows * ((N + 255) / 256)) < eff_rounds(rows * ((N + 127) / 128));
+}
+
 int g_balance_grid = 0;   // tuning hook: 1 = as few workgroups as finish in the same number of rounds
 // persistent grid: one workgroup per CU; balanced: ceil(tiles / rounds) rounded up to whole XCD groups
 inline int stream_grid(int total_tiles) {
@@ -1244,7 +1260,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     //   persistent 256x128 3-stage tiling is best (proj 125 us, fc2 284 us vs 127 / 310 for 128x128);
     //   small problems (head, tiny batches): 128x128.
     if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
-    else if (p.M >= 1024 && p.K >= 256) mode = 5;
+    else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N)) ? 4 : 5;
     else mode = 1;
   }
   static bool attr[6] = {false, false, false, false, false, false};   // [2] small, [3] wide, [4] mid, [5] wide4
