@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Race screen (guide: an early LDS read behind an LDS-DMA passes whenever the DMA happens to land first): every
 GEMM class, attention kernel, score+select and the whole forward are run many times on the same inputs, with the
-chip kept busy, and every result must equal the first one BIT FOR BIT.  python tools/soak.py [repeats]"""
+chip kept busy, and every result must equal the first one BIT FOR BIT.  python tools/soak.py [repeats] [noise]
+With "noise" a side stream keeps streaming 1 GiB copies and small matmuls while the screened kernel runs, so that
+memory latencies (and with them LDS-DMA landing times) wander."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rajni-vit_amd"))
@@ -11,14 +13,26 @@ from rajni_amd import ops, _native as nat, timm_shaped as ts
 
 dev = "cuda"
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+NOISE = len(sys.argv) > 2 and sys.argv[2] == "noise"
 bad = 0
+side = torch.cuda.Stream()
+na = torch.empty(1 << 28, dtype=torch.float32, device=dev); nb = torch.empty_like(na)
+nm = torch.randn(2048, 2048, device=dev).to(torch.bfloat16)
+
+def noise_burst():
+    with torch.cuda.stream(side):
+        nb.copy_(na)
+        for _ in range(4):
+            nm @ nm
 
 def screen(label, fn, reps):
     global bad
     first = fn()
     first = [t.clone() for t in (first if isinstance(first, (tuple, list)) else (first,)) if t is not None]
     n_bad = 0
-    for _ in range(reps):
+    for it in range(reps):
+        if NOISE and it % 8 == 0:
+            noise_burst()
         out = fn()
         out = [t for t in (out if isinstance(out, (tuple, list)) else (out,)) if t is not None]
         n_bad += not all(torch.equal(a, b) for a, b in zip(first, out))
