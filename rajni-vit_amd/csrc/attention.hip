@@ -653,7 +653,9 @@ constexpr int AG_VSTRIDE = 68;    // bf16 per V^T row (64 keys + 4)
 constexpr int AG_QROWS = 128;     // query rows per workgroup: 4 waves x 2 blocks of 16
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-__global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D) {
+template <int NW, int NB>   // waves per workgroup, blocks of 16 query rows per wave
+__global__ void __launch_bounds__(NW * 64, 2) attn_bf16_dgen(const AttnArgs a, int D) {
+  constexpr int NT = NW * 64, QROWS = NW * NB * 16, KI = 1024 / NT;   // K staging items per thread (<= 1024 per chunk)
   __shared__ __attribute__((aligned(16))) bf16_t sk[64 * AG_KSTRIDE];
   __shared__ __attribute__((aligned(16))) bf16_t svt[128 * AG_VSTRIDE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -665,12 +667,12 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
   const int* idx = a.idx ? a.idx + (long)b * np : nullptr;
 
   // a wave owns two blocks of 16 query rows: every K / V^T fragment read from LDS feeds two MFMAs
-  int q[2];
-  bool valid[2];
-  s16x4_t qf[2][8];                              // B operand of S^T: Q[q][16 kd + 4g + j]
+  int q[NB];
+  bool valid[NB];
+  s16x4_t qf[NB][8];                              // B operand of S^T: Q[q][16 kd + 4g + j]
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    q[u] = blockIdx.x * AG_QROWS + wave * 32 + u * 16 + r;
+  for (int u = 0; u < NB; ++u) {
+    q[u] = blockIdx.x * QROWS + (wave * NB + u) * 16 + r;
     valid[u] = q[u] < np;
     if (!valid[u]) q[u] = np - 1;
     const int srow = idx ? idx[q[u]] : q[u];
@@ -682,22 +684,24 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
       if (kd < ND && d0 < D) qf[u][kd] = *reinterpret_cast<const s16x4_t*>(qp + d0);   // D % 4 == 0: whole or nothing
     }
   }
-  f32x4 o[2][8];
+  f32x4 o[NB][8];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NB; ++u)
 #pragma unroll
     for (int db = 0; db < 8; ++db) o[u][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+  float m_run[NB], l_part[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) { m_run[u] = -INFINITY; l_part[u] = 0.f; }
   const int chunks8 = 2 * ND;                   // 8-element pieces per staged row (covering DP)
 
   // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before chunk c is
   // computed (up to 4 K pieces + 4 V pieces of 16 bytes per thread), so their latency hides under the MFMAs.
-  uint4 kreg[4], vreg[4];
+  uint4 kreg[KI], vreg[4];
   const int n_kitems = 64 * chunks8, n_vitems = 16 * chunks8;   // <= 1024 / <= 256
   auto fetch = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int item = tid + 256 * i;
+    for (int i = 0; i < KI; ++i) {
+      const int item = tid + NT * i;
       kreg[i] = make_uint4(0, 0, 0, 0);
       if (item < n_kitems) {
         const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
@@ -726,8 +730,8 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
   for (int c0 = 0; c0 < np; c0 += 64) {
     __syncthreads();                            // everyone is done reading the previous chunk
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int item = tid + 256 * i;
+    for (int i = 0; i < KI; ++i) {
+      const int item = tid + NT * i;
       if (item < n_kitems) {
         const int row = item / chunks8, d0 = (item - row * chunks8) * 8;
         *reinterpret_cast<uint4*>(sk + row * AG_KSTRIDE + d0) = kreg[i];
@@ -748,21 +752,23 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
     __syncthreads();
     if (c0 + 64 < np) fetch(c0 + 64);
 
-    f32x4 st[2][4];
-    float mloc[2] = {-INFINITY, -INFINITY};
+    f32x4 st[NB][4];
+    float mloc[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) mloc[u] = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      st[0][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[1][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NB; ++u) st[u][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kd = 0; kd < 8; ++kd)
         if (kd < ND) {
           const s16x4_t ka = *reinterpret_cast<const s16x4_t*>(sk + (16 * kb + r) * AG_KSTRIDE + 16 * kd + 4 * g);
-          st[0][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[0][kd], st[0][kb], 0, 0, 0);
-          st[1][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[1][kd], st[1][kb], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) st[u][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ka, qf[u][kd], st[u][kb], 0, 0, 0);
         }
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NB; ++u)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int key = c0 + 16 * kb + 4 * g + j;
@@ -771,10 +777,10 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
           mloc[u] = fmaxf(mloc[u], v);
         }
     }
-    float alpha[2];
-    s16x4_t pf[2][4];
+    float alpha[NB];
+    s16x4_t pf[NB][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NB; ++u) {
       float ml = fmaxf(mloc[u], __shfl_xor(mloc[u], 16, 64));
       ml = fmaxf(ml, __shfl_xor(ml, 32, 64));
       const float m_new = fmaxf(m_run[u], ml);      // finite: every chunk holds at least one real key
@@ -796,18 +802,18 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_dgen(const AttnArgs a, int D
 #pragma unroll
     for (int db = 0; db < 8; ++db)
       if (db < ND) {
-        o[0][db] *= alpha[0];
-        o[1][db] *= alpha[1];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) o[u][db] *= alpha[u];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const s16x4_t va = *reinterpret_cast<const s16x4_t*>(svt + (16 * db + r) * AG_VSTRIDE + 16 * kb + 4 * g);
-          o[0][db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[0][kb], o[0][db], 0, 0, 0);
-          o[1][db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[1][kb], o[1][db], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) o[u][db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pf[u][kb], o[u][db], 0, 0, 0);
         }
       }
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NB; ++u) {
     float l = l_part[u] + __shfl_xor(l_part[u], 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (valid[u]) {
@@ -1022,7 +1028,15 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
   ProfScope prof(KC_ATTENTION, s, flops, bytes);
   const int nsub = (np + 31) / 32;
   if (D != 64) {
-    hipLaunchKernelGGL(attn_bf16_dgen, dim3((np + AG_QROWS - 1) / AG_QROWS, H, B), dim3(256), 0, s, a, D);
+    #ifndef RAJNI_ATTN_DGEN_NW
+#define RAJNI_ATTN_DGEN_NW 4
+#endif
+#ifndef RAJNI_ATTN_DGEN_NB
+#define RAJNI_ATTN_DGEN_NB 2
+#endif
+    constexpr int qrows = RAJNI_ATTN_DGEN_NW * RAJNI_ATTN_DGEN_NB * 16;
+    hipLaunchKernelGGL((attn_bf16_dgen<RAJNI_ATTN_DGEN_NW, RAJNI_ATTN_DGEN_NB>), dim3((np + qrows - 1) / qrows, H, B),
+                       dim3(RAJNI_ATTN_DGEN_NW * 64), 0, s, a, D);
   } else if (nsub <= 8 && g_force_attn != 1) {
     int rc = RAJNI_OK;
     switch (nsub) {
