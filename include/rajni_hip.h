@@ -46,7 +46,8 @@ enum {
                               model.py:59 (mlp.fc2, ls2, add)                                       */
 };
 
-int rajni_abi_version(void);
+#define RAJNI_ABI_VERSION 4 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
+int rajni_abi_version(void); /* == RAJNI_ABI_VERSION of the header the library was built from */
 const char* rajni_last_error(void);
 /* 0 when a gfx950 device is usable by this process, else an error code (message in last_error) */
 int rajni_device_check(void);

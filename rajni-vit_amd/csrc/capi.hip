@@ -54,7 +54,7 @@ ProfScope::~ProfScope() {
 
 extern "C" {
 
-int rajni_abi_version(void) { return 4; }
+int rajni_abi_version(void) { return RAJNI_ABI_VERSION; }
 const char* rajni_last_error(void) { return g_err; }
 
 int rajni_device_check(void) {
