@@ -337,3 +337,20 @@ def test_patch_embed(S, P, Cc, B, has_cls, out_f32, tiling):
     else:
         want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok + pos[None]], axis=1)
     close(host(x), want, rel=1e-5 if out_f32 else 1e-2, what="patch embed")
+
+
+@pytest.mark.parametrize("Cin,S,P", [(1, 64, 16), (4, 32, 8), (1, 56, 14), (4, 28, 7), (2, 64, 32)])
+def test_patch_embed_other_channel_counts(Cin, S, P):
+    """in_chans other than 3 (grayscale, RGBA / multispectral): both the fused loader and the column path"""
+    rng = np.random.default_rng(Cin * 100 + P)
+    B, Cc = 3, 128
+    img = bf16_round_np(rng.standard_normal((B, Cin, S, S), dtype=np.float32))
+    w = bf16_round_np(rng.standard_normal((Cc, Cin, P, P), dtype=np.float32) * 0.05)
+    b = bf16_round_np(rng.standard_normal(Cc, dtype=np.float32) * 0.1)
+    cls = bf16_round_np(rng.standard_normal(Cc, dtype=np.float32))
+    pos = bf16_round_np(rng.standard_normal(((S // P) ** 2 + 1, Cc), dtype=np.float32))
+    x = ops.patch_embed(dev_bf16(img), ops.pack_weight(dev_bf16(w), k_multiple=64), torch.from_numpy(b).to(DEV), dev_bf16(cls),
+                        dev_bf16(pos), True, P, Cc, out_f32=True)
+    tok = orc.patch_embed(img.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    want = np.concatenate([np.broadcast_to(cls, (B, 1, Cc)), tok], axis=1) + pos[None]
+    close(host(x), want, rel=1e-5, what=f"patch embed Cin={Cin} P={P}")
