@@ -613,7 +613,9 @@ template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) +
 
 // NH = 64-column groups per wave: 1 = eight waves of (MI*16) x 64, 2 = FOUR waves of 128 x 128 (one per SIMD,
 // accumulators in the AGPR half of the register file; a third fewer LDS fragment bytes per MFMA)
-template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int NH = 1>
+// TAG does nothing in the body: residual launches with K <= N (the attention projection, bound by its fp32-stream
+// epilogue) run an instantiation of their own so that profilers list them apart from fc2, like bench.py's classes.
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int NH = 1, int TAG = 0>
 __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream(const GemmParams p) {
   using C = Cfg<WN * NH, NS, W8, WM * WN>;
   constexpr int NI = 4 * NH;                   // 16-column n-tiles per wave
@@ -1263,7 +1265,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N)) ? 4 : 5;
     else mode = 1;
   }
-  static bool attr[6] = {false, false, false, false, false, false};   // [2] small, [3] wide, [4] mid, [5] wide4
+  static bool attr[8] = {false, false, false, false, false, false, false, false};   // [2] small, [3] wide, [4] mid, [5] wide4, [6] [7] K<=N twins
   // algorithmic bytes: X + W + output (+ the residual rows read), fp32 where the residual stream is fp32
   constexpr double ysz = (SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH)) ? 4.0 : 2.0;
   constexpr double rsz = EPI == EPI_RESID ? (SF32 ? 4.0 : 2.0) : 0.0;
@@ -1274,12 +1276,19 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
+    if constexpr (EPI == EPI_RESID)
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, 1>, C::LDS_BYTES, attr[6])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);   // fp8 W: same blocks as bf16 (measured)
     p.rblk = g_rblk;
     const int grid = stream_grid(p.total_tiles);
-    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
+      if constexpr (EPI == EPI_RESID)
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    } else {
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    }
 #ifdef RAJNI_GEMM_WIDE4
   // Experiment (-DRAJNI_GEMM_WIDE4, tiling 6): the same 256x256x64 tile on FOUR waves of 128x128 (NH = 2; 256
   // VGPRs + 256 AGPRs, one wave per SIMD - the shape of hipBLASLt's MT256x256x64 kernel).  A third fewer LDS
@@ -1300,11 +1309,18 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+    if constexpr (EPI == EPI_RESID)
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, 1>, C::LDS_BYTES, attr[7])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2);
     p.rblk = g_rblk;
     const int grid = stream_grid(p.total_tiles);
-    hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
+      if constexpr (EPI == EPI_RESID)
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    } else {
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+    }
   } else {
     constexpr int lds = small::LDS_BYTES;
     if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>, lds, attr[2])) != RAJNI_OK) return rc;

@@ -12,6 +12,10 @@ rows = cur.execute("select name, duration from kernels").fetchall()
 agg = {}
 for name, dur in rows:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
+    if re.search(r"gemm_bf16_tn_stream<2,.*, 1>\(", name):     # TAG = 1: the K <= N residual launches (projection)
+        name += " [K<=N: bench class gemm_bf16_tn<bias,ls,resid> K<=N]"
+    elif re.search(r"gemm_bf16_tn_stream<2,", name):
+        name += " [K>N: bench class gemm_bf16_tn<bias,ls,resid>]"
     a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
     a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
 total = sum(a[1] for a in agg.values())

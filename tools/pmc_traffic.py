@@ -18,18 +18,16 @@ RESID_SQ = "gemm_bf16_tn<bias,ls,resid> K<=N"   # the projection: same kernel as
 
 
 def per_kernel(db_path, counter):
-    """{kernel name: (launches, sum KiB)}; the residual GEMM kernel is split by launch order into
-    '<name> [proj]' (even launches: a block runs proj, then fc2) and '<name> [fc2]'."""
+    """{kernel name: (launches, sum KiB)}; the K <= N residual launches (the projection) run an instantiation of
+    their own (template argument TAG = 1) and are listed as '<name> [proj]'."""
     cur = sqlite3.connect(db_path).cursor()
     rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ? order by dispatch_id",
                        (counter,)).fetchall()
-    out, seen = {}, {}
+    out = {}
     for name, v in rows:
         name = re.sub(r"\(anonymous namespace\)::", "", name)
-        if re.search(r"gemm_bf16_tn_(?:stream|128x128)<2,", name):
-            k = seen.get(name, 0)
-            seen[name] = k + 1
-            name += " [proj]" if k % 2 == 0 else " [fc2]"
+        if re.search(r"gemm_bf16_tn_stream<2,.*, 1>\(", name):
+            name += " [proj]"
         c, t = out.get(name, (0, 0.0))
         out[name] = (c + 1, t + v)
     return out
