@@ -1,3 +1,4 @@
+"""attention timing beyond 256 tokens (ViT-L/16 @384 stages: the chunked online-softmax kernel), GPU box only."""
 import sys
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch

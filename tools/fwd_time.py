@@ -1,3 +1,4 @@
+"""ms per 256-image ViT-B/16 forward (README schedule) with the library named by RAJNI_HIP_LIB; used by tools/ab_libs.sh."""
 import os, sys, time
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch, rajni_amd

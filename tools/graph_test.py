@@ -1,3 +1,4 @@
+"""whole-forward hipGraph capture: bit-identical logits and the time it buys (0.4 %: the path is not launch bound)."""
 import os, sys, time
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch, rajni_amd

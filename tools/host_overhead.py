@@ -1,3 +1,4 @@
+"""host-side cost of one RAJNIViTWrapper.forward call (plan lookup, weight-cache check, the native call), GPU box only."""
 import sys, time
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch, rajni_amd

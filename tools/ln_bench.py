@@ -1,3 +1,4 @@
+"""LayerNorm kernel alone on the forward's row counts: microseconds and TB/s (fp32 stream in, bf16 out)."""
 import sys
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch

@@ -1,3 +1,4 @@
+"""N-block size of the persistent GEMM tile order (rajni_debug_set_gemm_nblock_bytes) on the ViT-B GEMM shapes."""
 import sys, os
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch

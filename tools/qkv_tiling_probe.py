@@ -1,3 +1,4 @@
+"""QKV / FC1 (bf16-output GEMMs): 256x256 vs 256x128 tiling per token count at batch 256 and 64."""
 import sys, os, math
 sys.path.insert(0, "/root/repo/rajni-vit_amd")
 import torch
