@@ -5,8 +5,16 @@ README 4-stage schedule, batch 256 per GPU (BASELINE.json configs[1]; configs[2]
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one forward of one 256-image synthetic batch per GPU, images already resident in HBM
-(the reference's metric, rajni/eval.py:51-59, times exactly model(images) between two syncs).
+Without a launcher (`WORLD_SIZE` unset) and N > 1 this process NEVER touches a GPU: it checks that N devices are
+visible (exit 3 otherwise - there is no silent one-rank run), starts the N ranks itself through
+`torch.distributed.run`, relays rank 0's JSON line and exits with the launcher's status.
+
+A "step" is one forward of one 256-image synthetic batch per GPU, images already resident in HBM.
+`value` is the reference's metric exactly as rajni/eval.py:44-59,74 defines it: it comes out of
+`rajni_amd.evaluate_model` (per batch: sync -> model(images) -> sync, summed; SUM of images / MAX of seconds over
+the ranks), with every profiling hook off.  The K back-to-back forwards behind one sync (host enqueue hidden) are
+timed in a second region and reported as `pipelined_images_per_sec`; that second region is where the HIP-event
+kernel timing behind `roofline` runs.
 One JSON line on stdout (rank 0).  Extra objects:
   roofline     - dominant kernel (the packed-token MFMA GEMM), timed live with HIP events on the
                  launch stream inside the timed region (rajni_profile_* hooks of the C ABI);
@@ -30,6 +38,7 @@ import torch
 README_SCHEDULE = {3: {"keep_ratio": 0.88, "update": True}, 4: {"keep_ratio": 0.88, "update": True},
                    7: {"keep_ratio": 0.80, "update": True}, 8: {"keep_ratio": 0.72, "update": True}}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA (same table; never the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -91,15 +100,66 @@ def cpu_baseline(cfg, schedule, seconds_budget=20.0):
                       f"(usable cores of {os.cpu_count()} logical), {dt:.1f} s"}
 
 
-def main():
+def reference_agreement(dev, name="base224_agree256", chunk=64):
+    """"top-1 delta vs the reference wrapper" with resolution.  There are no trained weights or labels here, so the
+    statement is agreement with the REFERENCE'S OWN OUTPUTS on a committed fixture (tests/golden/make_golden.py
+    agreement_case): 256 seeded images, ViT-B/16 dims, README schedule, seeded weights; the reference's fp32 CPU
+    logits and per-stage keep_idx.  Reported: argmax agreement (eval.py:61-64 counts exactly that) and max |dlogit|,
+    absolute and relative to max |logit|, (a) with the reference's selections injected (selection-conditional parity,
+    SURVEY 4-3c) and (b) free-running (the device ranks its own bf16 scores); next to them the same two numbers for
+    the reference's own bf16 CPU run of the same images - the yardstick for what bf16 costs on this model."""
+    try:
+        import rajni_amd
+        from rajni_amd import timm_shaped as ts
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import load_case, case_images, pruned_blocks
+        meta, data = load_case(name)
+        fx = ts.create_model(ts.CONFIGS[meta["cfg_name"]], seed=meta["seed"], std=meta["std"],
+                             bias_std=meta["bias_std"], round_bf16=True)
+        fw = rajni_amd.RAJNIViTWrapper(fx, meta["schedule"]).to(dev).to(torch.bfloat16).eval()
+        images = torch.from_numpy(case_images(meta, data))
+        ref = data["logits"]
+        n = ref.shape[0]
+        scale = float(np.abs(ref).max())
+
+        def run(forced):
+            outs = []
+            for c in range(0, n, chunk):
+                fw.force_keep_idx({i: torch.from_numpy(data[f"blk{i}.keep_idx"][c:c + chunk].astype(np.int32)).to(dev)
+                                   for i in pruned_blocks(meta)} if forced else None)
+                outs.append(fw(images[c:c + chunk].to(dev)).float().cpu().numpy())
+            fw.force_keep_idx(None)
+            return np.concatenate(outs)
+
+        def cmp(got):
+            d = float(np.abs(got - ref).max())
+            return {"top1_agree": int((got.argmax(1) == ref.argmax(1)).sum()), "max_abs_dlogit": round(d, 5),
+                    "max_abs_dlogit_over_logit_scale": round(d / scale, 5)}
+
+        inj, free = run(True), run(False)
+        out = {"fixture": f"tests/golden/{name} (reference fp32 CPU run, ViT-B/16 dims, README schedule, seeded weights)",
+               "images": int(n), "logit_scale": round(scale, 4),
+               "median_top2_margin": round(float(meta.get("median_top2_margin", float("nan"))), 4),
+               "injected_selections": cmp(inj), "free_running": cmp(free),
+               "reference_own_bf16_run": {"top1_agree": int(meta["ref_bf16_top1_agree"]),
+                                          "max_abs_dlogit": round(float(meta["ref_bf16_max_abs_dlogit"]), 5),
+                                          "max_abs_dlogit_over_logit_scale": round(float(meta["ref_bf16_max_abs_dlogit"]) / scale, 5)},
+               "token_counts_equal": fw.get_last_stats()["token_counts"] == data["token_counts"].tolist()}
+        return out
+    except Exception as e:   # the bench line must not die on the side check
+        return {"error": repr(e)[:300]}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--model", default="vit_base_patch16_224")
-    ap.add_argument("--weight-format", default="model", choices=["model", "fp8"],
-                    help='"fp8": block Linear weights as e4m3 + per-row scale (BASELINE configs[4]); the headline '
+    ap.add_argument("--weight-format", default="model", choices=["model", "fp8", "fp8_mfma"],
+                    help='"fp8": block Linear weights as e4m3 + per-row scale feeding the bf16 MFMA; "fp8_mfma": e4m3 '
+                         'weights AND per-row-scaled e4m3 activations on the fp8 MFMA (BASELINE configs[4]); the headline '
                          'metric is quoted on "model" (bf16 weights)')
     ap.add_argument("--schedule", default=None,
                     help="JSON text or file {block: {keep_ratio, update}} (default: the README 4-stage schedule); "
@@ -108,24 +168,109 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def visible_gpus():
+    """Number of ROCm devices this process could use.  `torch.cuda.device_count()` only counts (it does not create a
+    HIP context), so the launcher parent stays off the GPU."""
+    return int(torch.cuda.device_count())
+
+
+def spawn_command(n, argv, port):
+    """The launcher line the driver itself uses for N > 1 (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher: start the N ranks and relay rank 0's line.  Runs BEFORE any GPU
+    call in this process.  Fewer than N visible devices is an error (exit 3), never a smaller run."""
+    import socket
+    import subprocess
+    one_device = os.environ.get("RAJNI_BENCH_ONE_DEVICE") == "1"    # rehearsal on a 1-GPU box, see worker()
+    need = 1 if one_device else args.gpus
+    have = visible_gpus()
+    if have < need:
+        print(f"bench.py: --gpus {args.gpus} needs {need} visible ROCm device(s), found {have}; refusing to run "
+              "a smaller job in its place", file=sys.stderr, flush=True)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(spawn_command(args.gpus, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                                 # ranks other than 0 print nothing on stdout
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr, flush=True)
+        rc = 4
+    return rc
+
+
+def latest_profile(suffix):
+    """Newest committed `profiles/rNN_<x>_<suffix>` (PMC counters cannot be read from inside this process; they come
+    from rocprofv3 passes over THIS command, made by tools/final_profile.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*" + suffix)))
+    return files[-1] if files else None
+
+
+class ResidentLoader:
+    """K (images, labels) batches already in HBM - the same resident batch K times (keep counts are data independent,
+    SURVEY Q1, so content does not affect timing)."""
+
+    def __init__(self, images, labels, n):
+        self.images, self.labels, self.n = images, labels, n
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield self.images, self.labels
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    return worker(args)
+
+
+def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report one as the other")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
     # rehearsal hooks for a 1-GPU box: RAJNI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # RAJNI_BENCH_BACKEND=gloo joins them over CPU tensors (RCCL refuses two ranks on one GPU)
-    if os.environ.get("RAJNI_BENCH_ONE_DEVICE") == "1":
+    one_device = os.environ.get("RAJNI_BENCH_ONE_DEVICE") == "1"
+    if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible")
     backend = os.environ.get("RAJNI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,7 +278,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)        # RCCL over xGMI when backend == "nccl"
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: all_reduce saw {ranks_seen} ranks, expected {world}")
 
+    import contextlib
     import rajni_amd
     from rajni_amd import timm_shaped as ts, _native as nat
 
@@ -149,14 +300,33 @@ def main():
     wrapped.set_weight_format(args.weight_format)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=gen, device=dev).to(torch.bfloat16)
+    labels = torch.randint(0, cfg.num_classes, (B,), generator=gen, device=dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def metric_run(m, steps):
+        """The metric as the reference defines it (eval.py:44-59,74) through the product's own harness: per batch
+        sync -> forward -> sync; under torch.distributed SUM(images) / MAX(seconds) over the ranks."""
+        with contextlib.redirect_stdout(sys.stderr):      # its "Warming up" line must not land on the result stream
+            _, ips = rajni_amd.evaluate_model(m, ResidentLoader(images, labels, steps), device=dev,
+                                              max_batches=steps, warmup=0)
+        return ips
+
+    # ---- headline: W untimed forwards, barrier + sync, K timed steps through evaluate_model, barrier + sync
+    nat.profile_enable(0)
     for _ in range(args.warmup):
         wrapped(images)
+    barrier()
+    w0 = time.perf_counter()
+    value = metric_run(wrapped, args.steps)               # already the whole-job figure (all-reduced inside)
+    barrier()
+    wall = time.perf_counter() - w0
+    counts = wrapped.get_last_stats()["token_counts"]
+
+    # ---- second region: K back-to-back forwards behind one sync, HIP-event timing of the GEMM classes on
     gemm_mask = 0b0111 | (1 << 12)  # the packed-token GEMM classes: qkv/head, fc1, fc2 (K > N), proj (K <= N)
     nat.profile_reset()
     nat.profile_enable(gemm_mask)
@@ -168,13 +338,12 @@ def main():
     elapsed = time.perf_counter() - t0
     nat.profile_enable(0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([elapsed, wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, wall = (float(v) for v in t.tolist())
     prof = nat.profile_collect()
-    counts = wrapped.get_last_stats()["token_counts"]
     # the HBM-bound part of the path (score -> top-k -> compact, the keep_idx gather fused into the attention
-    # loads, LayerNorm): HIP-event timing of a few extra forwards OUTSIDE the timed region
+    # loads, LayerNorm): HIP-event timing of a few extra forwards
     hbm_prof = {}
     if world == 1:
         nat.profile_reset()
@@ -188,40 +357,48 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
     fl_img, _ = flops_per_image(cfg, schedule)
-    value = world * B * args.steps / elapsed
-    # dominant kernel = the GEMM instantiation with the most time
+    fp8_mfma = args.weight_format == "fp8_mfma"
+    peak_tflops = PEAK_FP8_TFLOPS if fp8_mfma else PEAK_BF16_TFLOPS
     # BASELINE.json's metric is quoted on this workload; other --model/--schedule/--batch runs are labelled as such
     headline_workload = (args.model == "vit_base_patch16_224" and not args.schedule and args.batch == 256
                          and args.weight_format == "model")
     roofline = None
     if prof:
+        # dominant kernel = the GEMM instantiation with the most time
         name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = rec["ms"] / rec["launches"]
         achieved = rec["flops"] / rec["launches"] / (avg_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process;
-        # they were collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over THIS
-        # command and committed under profiles/ - null when that file does not cover the kernel
-        traffic = None
-        try:
-            if headline_workload:      # the PMC profile was taken over the default command only
-                with open(os.path.join(ROOT, "profiles", "r01_m_hbm_traffic_pmc.json")) as f:
+        traffic = traffic_src = mfma_busy = mfma_src = None
+        if headline_workload:      # the PMC profiles are taken over the default command only
+            try:
+                traffic_src = latest_profile("hbm_traffic_pmc.json")
+                with open(traffic_src) as f:
                     traffic = json.load(f)["by_bench_class"][name]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+            except Exception:
+                traffic = traffic_src = None
+            try:
+                mfma_src = latest_profile("mfma_pmc.json")
+                with open(mfma_src) as f:
+                    mfma_busy = json.load(f)["by_bench_class"][name]["mfma_busy_frac"]
+            except Exception:
+                mfma_busy = mfma_src = None
         # every GEMM class here is priced against the MFMA roof except the attention projection (K <= N),
         # whose 2 x M x N x 4 bytes of fp32 residual stream make it HBM bound (AI ~ 150 flop/B < the ~310 ridge)
         hbm_bound = "K<=N" in name
         gbps = rec["bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
+        rel = lambda pth: os.path.relpath(pth, ROOT) if pth else None
         roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
                     "achieved": round(gbps, 1) if hbm_bound else round(achieved, 1),
-                    "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                    "peak": PEAK_HBM_GBS if hbm_bound else peak_tflops,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / PEAK_BF16_TFLOPS, 4),
+                    "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / peak_tflops, 4),
                     "traffic": traffic,
-                    "traffic_source": "profiles/r01_m_hbm_traffic_pmc.json (rocprofv3 PMC, separate passes)" if traffic else None,
+                    "traffic_source": (rel(traffic_src) + " (rocprofv3 PMC, separate passes)") if traffic else None,
+                    "mfma_busy_frac": mfma_busy,
+                    "mfma_busy_source": (rel(mfma_src) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES)") if mfma_busy is not None else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": rec["launches"],
                     "all_gemm": {k: {"launches": v["launches"], "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
@@ -233,41 +410,33 @@ def main():
                        "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0),
                        "frac_of_hbm_peak": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
                    for k, v in hbm_prof.items() if v["launches"]}
+    wf = {"model": "", "fp8": " activations, fp8 e4m3 block weights (bf16 MFMA)",
+          "fp8_mfma": " stream, fp8 e4m3 block weights and per-row-scaled e4m3 activations (fp8 MFMA)"}[args.weight_format]
     out = {"metric": "images/sec ViT-B/16@224 with README schedule" if headline_workload
                      else f"images/sec {args.model} (not the BASELINE workload: see config.workload)",
            "value": round(value, 1), "unit": "images/sec",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"{args.model} bf16{' activations, fp8 e4m3 block weights' if args.weight_format == 'fp8' else ''}, "
+           "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(world * B / value * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp8" if fp8_mfma else "bf16", "data": "synthetic",
+           "timing": "rajni_amd.evaluate_model: sum over K batches of (sync -> forward -> sync), reference eval.py:51-59,74; "
+                     "MAX over ranks; profiling hooks off",
+           "wall_ms_per_step": round(wall / args.steps * 1e3, 3),
+           "pipelined_images_per_sec": round(world * B * args.steps / elapsed, 1),
+           "pipelined_ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "config": {"workload": f"{args.model} bf16{wf}, "
                                   f"batch {B}/GPU, {'README 4-stage schedule {3:.88,4:.88,7:.80,8:.72}' if not args.schedule else 'schedule ' + json.dumps({k: v['keep_ratio'] for k, v in schedule.items()})}, "
                                   f"synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
-                      "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}"},
+                      "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}",
+                      "collective": (f"{backend} all_reduce of [correct,total,images] (SUM) and seconds (MAX), once per run"
+                                     if world > 1 else None)},
            "model_tflops": round(value * fl_img / 1e12, 1),
-           "model_mfma_frac": round(value * fl_img / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+           "model_mfma_frac": round(value * fl_img / 1e12 / (peak_tflops * world), 4),
            "roofline": roofline}
 
     if headline_workload and world == 1:
-        # "top-1 delta vs the reference wrapper": there are no trained weights or labels here, so what can be stated is
-        # agreement with the reference's own outputs on the committed fixture (same model dims and schedule, seeded
-        # weights, reference selections injected - tests/test_gpu_forward.py holds the same comparison to 1e-2)
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from helpers import load_case, case_images, pruned_blocks
-            meta, data = load_case("base224_fp32")
-            fx = ts.create_model(ts.CONFIGS[meta["cfg_name"]], seed=meta["seed"], std=meta["std"],
-                                 bias_std=meta["bias_std"], round_bf16=True)
-            fw = rajni_amd.RAJNIViTWrapper(fx, meta["schedule"]).to(dev).to(torch.bfloat16).eval()
-            fw.force_keep_idx({i: torch.from_numpy(data[f"blk{i}.keep_idx"]).to(dev) for i in pruned_blocks(meta)})
-            got = fw(torch.from_numpy(case_images(meta, data)).to(dev)).float().cpu().numpy()
-            ref = data["logits"]
-            out["reference_agreement"] = {
-                "fixture": "tests/golden/base224_fp32 (reference fp32 CPU run, ViT-B/16 dims, README schedule)",
-                "images": int(ref.shape[0]), "top1_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
-                "max_abs_dlogit_over_logit_scale": round(float(abs(got - ref).max() / abs(ref).max()), 5),
-                "token_counts_equal": fw.get_last_stats()["token_counts"] == data["token_counts"].tolist()}
-        except Exception as e:   # the bench line must not die on the side check
-            out["reference_agreement"] = {"error": repr(e)[:200]}
+        out["reference_agreement"] = reference_agreement(dev)
     if hbm_kernels:
         # algorithmic bytes: score+select reads the K and V thirds of qkv once ((2NC + C) x 2 B per image) and writes
         # indices/scores; attention reads the kept q, k, v rows through keep_idx and writes the output (the
@@ -280,27 +449,15 @@ def main():
         wrapped.set_last_block_cls_only(True)
         for _ in range(3):
             wrapped(images)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            wrapped(images)
-        torch.cuda.synchronize(dev)
-        out["cls_only_last_block_images_per_sec"] = round(B * args.steps / (time.perf_counter() - t0), 1)
+        out["cls_only_last_block_images_per_sec"] = round(metric_run(wrapped, args.steps), 1)
         wrapped.set_last_block_cls_only(False)
     if world == 1 and not args.no_torch_baseline:
-        # the "4x" denominator: unpruned timm-shaped base, stock PyTorch-ROCm ops, same batch
+        # the "4x" denominator: unpruned timm-shaped base, stock PyTorch-ROCm ops, same batch, same harness
         base = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev).eval()
         with torch.no_grad():
             for _ in range(3):
                 base(images)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            nb = max(3, min(args.steps, 10))
-            for _ in range(nb):
-                base(images)
-            torch.cuda.synchronize(dev)
-            tb = time.perf_counter() - t0
-        base_ips = B * nb / tb
+        base_ips = metric_run(base, max(3, min(args.steps, 10)))
         out["unpruned_torch_images_per_sec"] = round(base_ips, 1)
         out["speedup_vs_unpruned_torch"] = round(value / base_ips, 3)
         del base
@@ -309,7 +466,8 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -83,9 +83,6 @@ int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int
  * kernels; other head dims take a general MFMA kernel). */
 int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                     int H, int D, float scale, int dtype, rajni_stream_t stream);
-/* test hook: 0 = choose by np (default: persistent full-row kernel for np <= 256), 1 = chunked online-softmax
- * kernel, 2 = one-shot full-row kernel (np <= 256) */
-void rajni_debug_force_attention(int mode);
 
 /* ---- LayerNorm over the last axis (blk.norm1 / norm2 / m.norm)            model.py:51,59,65 ----
  * x rows are `x_row_stride` elements apart (lets the final norm read CLS rows only), y is dense
@@ -118,21 +115,6 @@ typedef struct {
   const float* w_scale;
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
-/* test hook: 0 = choose the GEMM tiling by shape (default), 1 = 128x128x64 (4 waves), 4 = 256x256x64 persistent,
- * 5 = 256x128x64 3-stage persistent */
-void rajni_debug_force_gemm_tiling(int mode);
-/* test hook / tuning: W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the
- * plain column-fastest order; -k = blocks of k column tiles regardless of size */
-void rajni_debug_set_gemm_nblock_bytes(int bytes);
-/* tuning hook: second level of that order - super-blocks of `row_tiles` 256-row tiles, each walked (N block, row
- * tile, column) before the next one starts (0 = one super-block spanning all rows, the default) */
-void rajni_debug_set_gemm_row_superblock(int row_tiles);
-/* tuning hook: 1 = launch the persistent GEMMs with the smallest grid that still finishes in the same number
- * of tile rounds (a multiple of 8 workgroups), 0 = one workgroup per CU (default) */
-void rajni_debug_set_gemm_balanced_grid(int on);
-/* diagnostic builds (-DRAJNI_GEMM_STAMPS) only: device buffer receiving 4 x uint64 s_memtime stamps per
- * workgroup of the 256x256 GEMM (start, main loop start, main loop end, end); NULL disables */
-void rajni_debug_set_gemm_stamps(void* buf);
 
 /* ---- a12: patch-embed + CLS + pos-embed                                    model.py:34-37 ----
  * images [B,Cin,S,S] -> x [B, 1+(S/P)^2, C].  conv weight w [C(pad256), ceil64(Cin*P*P)] (k order c,ky,kx,

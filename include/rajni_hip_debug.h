@@ -1,0 +1,31 @@
+/* rajni_hip_debug.h - test and tuning hooks of librajni_hip.so.  NOT part of the drop-in boundary
+ * (include/rajni_hip.h): nothing on the product path calls these.  They set process-global, unsynchronised
+ * switches, so they must not be flipped while another thread is inside a rajni_* call; the tests and the
+ * probes under tools/ use them from one thread, before the launch they want to steer. */
+#ifndef RAJNI_HIP_DEBUG_H
+#define RAJNI_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* attention kernel choice: 0 = by np (default: persistent full-row kernel for np <= 256), 1 = chunked
+ * online-softmax kernel, 2 = one-shot full-row kernel (np <= 256) */
+void rajni_debug_force_attention(int mode);
+
+/* GEMM tiling: 0 = by shape (default), 1 = 128x128x64 (4 waves), 4 = 256x256x64 persistent,
+ * 5 = 256x128x64 3-stage persistent */
+void rajni_debug_force_gemm_tiling(int mode);
+
+/* W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the plain column-fastest
+ * order; -k = blocks of k column tiles regardless of size.  Results are bit-identical for every value (tested). */
+void rajni_debug_set_gemm_nblock_bytes(int bytes);
+
+/* diagnostic builds (-DRAJNI_GEMM_STAMPS / -DRAJNI_ATTN_STAMPS / -DRAJNI_SS_STAMPS) only: device buffer receiving
+ * 4 x uint64 s_memtime stamps per workgroup; NULL disables */
+void rajni_debug_set_gemm_stamps(void* buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

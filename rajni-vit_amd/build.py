@@ -16,7 +16,8 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "rajni_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h)
+                                                               for h in ("rajni_hip.h", "rajni_hip_debug.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

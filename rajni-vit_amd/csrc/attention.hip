@@ -912,7 +912,8 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
     return RAJNI_OK;
   }
   constexpr int lds = NSUB * 32 * 256 * 2 + (stage_o(NSUB) ? 8 * 4096 : 0);   // two K+V buffers (+ output staging)
-  static bool attr = false;
+  static bool attr_by_device[RAJNI_MAX_DEVICES] = {};
+  bool& attr = attr_by_device[rajni_current_device()];
   if (!attr && lds > 64 * 1024) {
     for (const void* fn : {reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, false>),
                            reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, true>)}) {
@@ -923,7 +924,8 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
   }
   const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;   // 512-thread workgroups resident per CU
   const int items = a.H * B;
-  const int grid = items < 256 * per_cu ? items : 256 * per_cu;
+  const int cus = rajni_num_cus();
+  const int grid = items < cus * per_cu ? items : cus * per_cu;
   if (a.idx != nullptr)
     hipLaunchKernelGGL((attn_bf16_d64_stream<NSUB, true>), dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
   else

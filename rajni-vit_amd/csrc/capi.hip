@@ -30,6 +30,22 @@ const char* const kNames[RAJNI_NUM_KCLASS] = {
 
 unsigned long long* rajni_g_stamps = nullptr;
 
+int rajni_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RAJNI_MAX_DEVICES) return 0;
+  return dev;
+}
+int rajni_num_cus() {
+  static int cus[RAJNI_MAX_DEVICES] = {};     // 0 = not read yet (benign race: every writer stores the same value)
+  const int dev = rajni_current_device();
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 void rajni_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/rajni_hip.h"
+#include "../../include/rajni_hip_debug.h"
 
 typedef unsigned short bf16_t;  // raw bf16 bits in memory
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -78,6 +79,11 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- host side -----------------------------------------------------------------------------
 void rajni_set_error(const char* fmt, ...);
+// the device the calling thread's launches go to, and its CU count (hipDeviceProp_t::multiProcessorCount,
+// read once per device; 256 on MI355X).  Per-device caches are sized RAJNI_MAX_DEVICES.
+#define RAJNI_MAX_DEVICES 32
+int rajni_current_device();
+int rajni_num_cus();
 
 enum KClass {
   KC_GEMM_BIAS = 0, KC_GEMM_GELU = 1, KC_GEMM_RESID = 2, KC_GEMM_PATCH = 3, KC_ATTENTION = 4,

@@ -20,11 +20,10 @@
 //   mid   256 x 128 x 64, 8 waves, 3 LDS stages, persistent stream  - N = 768-class outputs (proj, fc2)
 //   small 128 x 128 x 64, 4 waves, 2 stages, 2 workgroups per CU    - M < 1024 (head, tiny batches)
 //   f32   128 x 128 x 32(fp32) on v_mfma_f32_16x16x4_f32            - fp32 models
-// (Two further tilings, 256x128x32 and 128x128x32 with 3 stages of 64-byte rows, were built and
-//  measured in round 1 and removed: half-line DMA pieces made them slower than `small` on every shape.
-//  Build-time experiments kept behind macros, all off: RAJNI_GEMM_WIDE4 - the wide tile on four waves of
-//  128x128; RAJNI_GEMM_PINGPONG - different issue patterns for the two waves of a SIMD; RAJNI_GEMM_READ_FRONT,
-//  RAJNI_GEMM_DMA_FRONT, RAJNI_GEMM_EPI_NT, RAJNI_GEMM_X_AUX / W_AUX - DESIGN.md section 4 has the numbers.)
+// (Measured in round 1 and removed from this file, numbers in DESIGN.md section 4: 256x128x32 / 128x128x32
+//  tilings with 64-byte rows, the wide tile on four waves of 128x128, per-SIMD-partner issue patterns,
+//  front-loaded fragment reads / DMA, non-temporal epilogue accesses, cache-policy bits on the DMA loads, row
+//  super-blocks in the tile order, round-balanced grids.)
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -46,7 +45,6 @@ struct GemmParams {
   int M, N, K;
   int tiles_n, total_tiles;
   int nblk;                     // persistent tilings: column tiles per N block of the tile order (tile_mn)
-  int rblk;                     // ... row tiles per super-block (0: one super-block = all rows)
   // patch-embed A loader / epilogue
   int cin, S, log2ps, gw, npatch;
   const void* pos; int pos_off; // pos-embed rows, activation dtype
@@ -301,26 +299,8 @@ __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int
 // many loads are in flight and how much of their latency hides under MFMAs.  Measured on proj
 // (tools/proj_probe.py): 155 us -> 135 us with all loads of the tile issued before the first store,
 // -> (see profiles) with the loads issued one K step before the epilogue.
-// fp32 residual stream accesses of the interior-tile fast path: read once, written once, next touched by a
-// LayerNorm launch - RAJNI_GEMM_EPI_NT bit 0 = non-temporal stores, bit 1 = non-temporal loads (experiment)
-#ifndef RAJNI_GEMM_EPI_NT
-#define RAJNI_GEMM_EPI_NT 0
-#endif
-typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldg_stream(const float4* p) {
-  if constexpr ((RAJNI_GEMM_EPI_NT & 2) != 0) {
-    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-  } else {
-    return *p;
-  }
-}
-__device__ __forceinline__ void stg_stream(float4* p, const float4& v) {
-  if constexpr ((RAJNI_GEMM_EPI_NT & 1) != 0)
-    __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
-  else
-    *p = v;
-}
+// (default cache policy on purpose: non-temporal loads / stores here cost 1-2 % of the forward - the LayerNorm
+// launch that reads the stream next profits from the lines the default policy leaves in L2)
 template <int MI>
 struct ResidPrefetch {
   float4 r[MI][4];
@@ -340,7 +320,7 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
         if (p.ridx != nullptr) rrow = (long)(m / p.r_np) * p.r_nsrc + p.ridx[m];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          pre.r[mi][ni] = ldg_stream(reinterpret_cast<const float4*>(R + rrow * p.ldr + n0w + 16 * ni + 4 * g));
+          pre.r[mi][ni] = *reinterpret_cast<const float4*>(R + rrow * p.ldr + n0w + 16 * ni + 4 * g);
       }
       pre.valid = true;
     }
@@ -435,7 +415,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           o.y = fmaf(gam[4 * ni + 1], acc[ni][mi][1] + bias[4 * ni + 1], pre.r[mi][ni].y);
           o.z = fmaf(gam[4 * ni + 2], acc[ni][mi][2] + bias[4 * ni + 2], pre.r[mi][ni].z);
           o.w = fmaf(gam[4 * ni + 3], acc[ni][mi][3] + bias[4 * ni + 3], pre.r[mi][ni].w);
-          stg_stream(reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g), o);
+          *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g) = o;
         }
       return;
     }
@@ -506,18 +486,7 @@ struct XSource {
 // early), so the next tile's first loads fly during the epilogue.  One raw s_barrier per K step;
 // every LDS read and DMA issue sits between MFMAs (sched_group_barrier pins the order).
 // =============================================================================================
-#ifndef RAJNI_GEMM_X_AUX
-#define RAJNI_GEMM_X_AUX 0   // cache-policy bits of the X (activation) LDS-DMA loads: 2 = nt
-#endif
-#ifndef RAJNI_GEMM_W_AUX
-#define RAJNI_GEMM_W_AUX 0   // ... of the W (weight) loads
-#endif
-#ifndef RAJNI_GEMM_NBLK_BYTES
 #define RAJNI_GEMM_NBLK_BYTES (1600 * 1024)
-#endif
-#ifndef RAJNI_GEMM_RELAX_FIRST
-#define RAJNI_GEMM_RELAX_FIRST 1
-#endif
 namespace wide {
 constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
@@ -536,27 +505,10 @@ template <int WN_, int NS_, bool W8_ = false, int NW_ = 8> struct Cfg {   // WN_
   static constexpr int NPW = PW < (W8_ ? 2 : 4) ? PW : (W8_ ? 2 : 4);
 };
 
-// first DMA piece issued after MFMA group g of a half step.  RAJNI_GEMM_DMA_FRONT pieces per group
-// until they run out (front-loaded: the pieces must land by the NEXT mid-step barrier, so the earlier
-// in the half step they are issued the more of their latency is hidden); 0 = spread evenly
-#ifndef RAJNI_GEMM_DMA_FRONT
-#define RAJNI_GEMM_DMA_FRONT 0
-#endif
-__host__ __device__ constexpr int dma_first(int g, int pieces, int groups) {
-  return RAJNI_GEMM_DMA_FRONT > 0 ? (g * RAJNI_GEMM_DMA_FRONT < pieces ? g * RAJNI_GEMM_DMA_FRONT : pieces)
-                                  : g * pieces / groups;
-}
-// issue order of one half step: MI groups of {4 MFMAs, fragment reads, DMA pieces}
-// fragment reads issued after MFMA group g of a half step: spread evenly (0), or RAJNI_GEMM_READ_FRONT per
-// group until they run out - the reads of a half step feed the NEXT one and the stage they come from is
-// released (lgkmcnt(0) + barrier) at its end, so reads issued in the last groups expose their latency there
-#ifndef RAJNI_GEMM_READ_FRONT
-#define RAJNI_GEMM_READ_FRONT 0
-#endif
-__host__ __device__ constexpr int rd_first(int g, int mi, int ni) {
-  return RAJNI_GEMM_READ_FRONT > 0 ? (g * RAJNI_GEMM_READ_FRONT < mi + ni ? g * RAJNI_GEMM_READ_FRONT : mi + ni)
-                                   : g + g * ni / mi;
-}
+// issue order of one half step: MI groups of {NI MFMAs, 1-2 fragment reads, DMA pieces}, reads and pieces spread
+// evenly over the groups (front-loading either was measured and is slower: the forward 9.03 -> 9.45 ms)
+__host__ __device__ constexpr int dma_first(int g, int pieces, int groups) { return g * pieces / groups; }
+__host__ __device__ constexpr int rd_first(int g, int mi, int ni) { return g + g * ni / mi; }
 template <int G, int MI, bool DMA, int PIECES, int NI = 4>
 __device__ __forceinline__ void sched_half() {
   if constexpr (G < MI) {
@@ -570,58 +522,21 @@ __device__ __forceinline__ void sched_half() {
     sched_half<G + 1, MI, DMA, PIECES, NI>();
   }
 }
-// Issue patterns of a half step.  0: MI groups of {NI MFMAs, 1-2 fragment reads, DMA pieces} (sched_half, the
-// default for every wave).  Experiment RAJNI_GEMM_PINGPONG: the two waves that share a SIMD (w and w + 4) get
-// DIFFERENT patterns so that one streams its MFMAs while the other issues its LDS reads and DMA - pattern 1: all
-// reads and DMA first, then the MFMAs; pattern 2: RAJNI_GEMM_PP_SPLIT MFMA groups, the reads and DMA, the rest.
-#ifndef RAJNI_GEMM_PINGPONG
-#define RAJNI_GEMM_PINGPONG 0
-#endif
-#ifndef RAJNI_GEMM_PP_SPLIT
-#define RAJNI_GEMM_PP_SPLIT 5
-#endif
-// MFMA groups [G0, G1) with their DMA pieces (no fragment reads)
-template <int G, int G1, int MI, bool DMA, int PIECES, int NI>
-__device__ __forceinline__ void sched_mfma_dma() {
-  if constexpr (G < G1) {
-    __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
-    if constexpr (DMA) {
-      constexpr int nd = dma_first(G + 1, PIECES, MI) - dma_first(G, PIECES, MI);
-      if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
-    }
-    sched_mfma_dma<G + 1, G1, MI, DMA, PIECES, NI>();
-  }
-}
-template <int PAT, int MI, bool DMA, int PIECES, int NI>
-__device__ __forceinline__ void sched_pattern() {
-  if constexpr (PAT == 0) {
-    sched_half<0, MI, DMA, PIECES, NI>();
-  } else if constexpr (PAT == 1) {
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-    sched_mfma_dma<0, MI, MI, DMA, PIECES, NI>();
-  } else {
-    constexpr int split = RAJNI_GEMM_PP_SPLIT < MI ? RAJNI_GEMM_PP_SPLIT : MI - 1;
-    sched_mfma_dma<0, split, MI, DMA, PIECES, NI>();
-    __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-    sched_mfma_dma<split, MI, MI, DMA, PIECES, NI>();
-  }
-}
 template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) + counted vmcnt
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
 }
 
-// NH = 64-column groups per wave: 1 = eight waves of (MI*16) x 64, 2 = FOUR waves of 128 x 128 (one per SIMD,
-// accumulators in the AGPR half of the register file; a third fewer LDS fragment bytes per MFMA)
+// Eight waves of (MI*16) x 64 outputs each.
 // TAG does nothing in the body: residual launches with K <= N (the attention projection, bound by its fp32-stream
 // epilogue) run an instantiation of their own so that profilers list them apart from fc2, like bench.py's classes.
-template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int NH = 1, int TAG = 0>
-__global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream(const GemmParams p) {
-  using C = Cfg<WN * NH, NS, W8, WM * WN>;
-  constexpr int NI = 4 * NH;                   // 16-column n-tiles per wave
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int TAG = 0>
+__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const GemmParams p) {
+  using C = Cfg<WN, NS, W8, WM * WN>;
+  constexpr int NI = 4;                        // 16-column n-tiles per wave
   using WFrag = typename WFragT<W8>::type;   // a W fragment as it sits in LDS: 8 bf16, or 8 fp8 bytes
   constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
-  static_assert((WM * WN == 8 || WM * WN == 4) && WM * MI * 16 == BM, "4 or 8 waves covering 256 rows");
+  static_assert(WM * WN == 8 && WM * MI * 16 == BM, "8 waves covering 256 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,20 +562,10 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
   const int tiles_m = p.total_tiles / p.tiles_n;
   auto tile_mn = [&](int t, int& tm_, int& tn_) {
     if (p.nblk >= p.tiles_n) { tm_ = t / p.tiles_n; tn_ = t - tm_ * p.tiles_n; return; }
-    // optional second level: super-blocks of rblk row tiles, inside each the (block, row tile, column) order -
-    // the X panels of a super-block are meant to stay in L2 across its N blocks instead of being streamed once
-    // per block over all of M
-    int row0 = 0, rows = tiles_m;
-    if (p.rblk > 0 && p.rblk < tiles_m) {
-      const int sbsz = p.rblk * p.tiles_n, sb = t / sbsz;
-      t -= sb * sbsz;
-      row0 = sb * p.rblk;
-      rows = tiles_m - row0 < p.rblk ? tiles_m - row0 : p.rblk;
-    }
-    const int per = p.nblk * rows, blk = t / per, r = t - blk * per;
+    const int per = p.nblk * tiles_m, blk = t / per, r = t - blk * per;
     const int left = p.tiles_n - blk * p.nblk, nb = left < p.nblk ? left : p.nblk;
     const int rr = r / nb;
-    tm_ = row0 + rr; tn_ = blk * p.nblk + (r - rr * nb);
+    tm_ = rr; tn_ = blk * p.nblk + (r - rr * nb);
   };
   XSource<ALOAD> xs[ALOAD == ALOAD_PLAIN ? 1 : C::XP];   // fused im2col loader: one source per piece
   const char* xp[2];                                 // plain loader: even and odd pieces (16 rows apart each)
@@ -713,16 +618,16 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
     if (q < C::XP) {
       if constexpr (ALOAD == ALOAD_PLAIN)
         __builtin_amdgcn_global_load_lds(GLB_PTR(xp[q & 1] + ((long)(q >> 1) * 16 * p.lda + k0) * 2),
-                                         LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+                                         LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, 0);
       else
-        __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, RAJNI_GEMM_X_AUX);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xs[q].at(p, k0)), LDS_PTR(dx + (wave * C::XP + q) * 1024), 16, 0, 0);
     } else {
       const int i = q - C::XP;   // W piece i: pointer i % NPW, (i / NPW) * 32 tile rows further down
       if constexpr (C::PW <= C::NPW)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i] + k0 * C::WB), LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, 0);
       else
         __builtin_amdgcn_global_load_lds(GLB_PTR(ws[i % C::NPW] + ((long)(i / C::NPW) * 32 * p.ldw + k0) * C::WB),
-                                         LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, RAJNI_GEMM_W_AUX);
+                                         LDS_PTR(dx + X_BYTES + (wave * C::PW + i) * 1024), 16, 0, 0);
     }
   };
   auto stage = [&](int kt, int st) {
@@ -735,10 +640,9 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
   const int xr0 = wm * (MI * 16) + l15;
-  const int wr0 = wn * (64 * NH) + w_frag_row<MAP>(l15, 0);
-  // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same);
-  // n-tiles 4.. are the wave's second 64-column group = 64 tile rows further down
-  auto w_ni_off = [](int ni) { return ((ni >> 2) * 64 + w_frag_row<MAP>(0, ni & 3) - w_frag_row<MAP>(0, 0)) * (64 * C::WB); };
+  const int wr0 = wn * 64 + w_frag_row<MAP>(l15, 0);
+  // byte offset of n-tile ni's W rows from n-tile 0's (lane independent; the swizzle key is the same)
+  auto w_ni_off = [](int ni) { return (w_frag_row<MAP>(0, ni) - w_frag_row<MAP>(0, 0)) * (64 * C::WB); };
   int xo[2], wo[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -749,14 +653,13 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
       wo[ks] = X_BYTES + wr0 * 128 + (((ks * 4 + g) ^ w_key<MAP>(wr0)) << 4);
   }
 
-  f32x4 acc[NH][4][MI];  // [column group][ni][mi]
+  f32x4 acc[4][MI];  // [ni][mi]
 
   // one half step: MFMAs on (xc,wc) || fragments (stage rst, sub-step rks) -> (xn,wn_), xn[mi] issued
   // right after the group that consumed xc[mi] || if DMA: K-tile dkt of the pointed-at tile -> stage dst
-  auto half = [&](auto dma_c, auto pat_c, bf16x8 (&xc)[MI], WFrag (&wc)[NI], bf16x8 (&xn)[MI], WFrag (&wn_)[NI],
+  auto half = [&](auto dma_c, bf16x8 (&xc)[MI], WFrag (&wc)[NI], bf16x8 (&xn)[MI], WFrag (&wn_)[NI],
                   int rst, int rks, int dkt, int dst) {
     constexpr bool DMA = decltype(dma_c)::value;
-    constexpr int PAT = decltype(pat_c)::value;
     const char* sb = smem + rst * C::STAGE_BYTES;
     char* dx = smem + dst * C::STAGE_BYTES;
     const int k0 = dkt * BK;
@@ -767,7 +670,7 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[ni >> 2][ni & 3][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ni], xc[mi], acc[ni >> 2][ni & 3][mi], 0, 0, 0);
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[ni], xc[mi], acc[ni][mi], 0, 0, 0);
       xn[mi] = *reinterpret_cast<const bf16x8*>(sb + xo[rks] + mi * 2048);
 #pragma unroll
       for (int wi = mi * NI / MI; wi < (mi + 1) * NI / MI; ++wi)
@@ -777,13 +680,9 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
         for (int q = dma_first(mi, C::PIECES, MI); q < dma_first(mi + 1, C::PIECES, MI); ++q) dma_piece(q, k0, dx);
       }
     }
-    sched_pattern<PAT, MI, DMA, C::PIECES, NI>();
+    sched_half<0, MI, DMA, C::PIECES, NI>();
   };
   using T = std::true_type; using F = std::false_type;
-  using P0 = std::integral_constant<int, 0>;
-  using PA = std::integral_constant<int, RAJNI_GEMM_PINGPONG / 10>;    // waves 0..3   (RAJNI_GEMM_PINGPONG = 10 a + b)
-  using PB = std::integral_constant<int, RAJNI_GEMM_PINGPONG % 10>;    // waves 4..7
-  const bool second_group = wave >= WM * WN / 2;
 
   const int nk = p.K / BK;        // >= NS + 1 (host checked)
   int v = blockIdx.x;
@@ -813,14 +712,10 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
   // vmcnt as well and retires vector-memory ops in order, so the first counted wait of a tile may leave
   // exactly the epilogue's stores outstanding instead of waiting for them to reach L2: an interior tile's
   // epilogue issues NSTORE stores per wave after the DMA of K step 1 (a lower bound is all that is needed).
-  constexpr int NSTORE_ALL = RAJNI_GEMM_RELAX_FIRST ? (nat_order(EPI, SF32) ? 4 * MI : 2 * MI) * NH : 0;
+  constexpr int NSTORE_ALL = nat_order(EPI, SF32) ? 4 * MI : 2 * MI;
   constexpr int NSTORE = NSTORE_ALL < 48 ? NSTORE_ALL : 48;   // vmcnt is a 6-bit counter
   bool prev_full = false;          // the previous tile of this workgroup was interior
 
-  // the whole persistent loop per issue pattern: branching per half step instead would merge the two paths'
-  // accumulators after every half (measured: +70 VGPRs, 528 bytes of spills in the wide tiling)
-  auto run = [&](auto pat_c) {
-  using PAT = decltype(pat_c);
   while (true) {
 #ifdef RAJNI_GEMM_STAMPS
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
@@ -834,11 +729,9 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
     const bool more = vn < p.total_tiles;
     pre.valid = false;
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
       // the DMA of step kt loads K-tile kt+NS; from kt = nk-NS on that is the NEXT tile's K-tile
@@ -846,27 +739,23 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
       if (kt == nk - NS && more) advance(tile, xcd_tile_of(vn, p.total_tiles));
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
-      if (NH == 1 && kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
-      half(F{}, PAT{}, xa, wa, xb, wb, st, 1, 0, 0);
+      if (kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
+      half(F{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
       if (NSTORE > 0 && kt == 0 && prev_full) wait_step<WBASE + NSTORE>();
       else wait_step<WBASE>();
       __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
-      half(T{}, PAT{}, xb, wb, xa, wa, st1, 0, dkt, st);
+      half(T{}, xb, wb, xa, wa, st1, 0, dkt, st);
       st = st1;
     }
 #ifdef RAJNI_GEMM_STAMPS
-    asm volatile("" :: "v"(acc[0][0][0][0]), "v"(acc[NH - 1][3][MI - 1][3]));
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][MI - 1][3]));
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    // (written out, not a loop over h: a loop here - even one fully unrolled later - changes the order hipcc
-    // optimises in and costs the eight-wave instantiations 10-20 VGPRs, i.e. spills in the GELU epilogue)
-    epilogue_tile<EPI, SF32, MI, W8>(p, acc[0], m0 + wm * (MI * 16), n0 + wn * NH * 64, l15, g, pre, m_lo, inter);
-    if constexpr (NH == 2)
-      epilogue_tile<EPI, SF32, MI, W8>(p, acc[1], m0 + wm * (MI * 16), n0 + wn * NH * 64 + 64, l15, g, pre, m_lo, inter);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -880,13 +769,6 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) gemm_bf16_tn_stream
     if (!more) break;
     v = vn;
     tile = xcd_tile_of(v, p.total_tiles);
-  }
-  };
-  if constexpr (RAJNI_GEMM_PINGPONG != 0) {
-    if (second_group) run(PB{});
-    else run(PA{});
-  } else {
-    run(P0{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing (unused) DMA before LDS is released
 }
@@ -1001,8 +883,12 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
 }
 }  // namespace small
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `done` is the calling site's
+// per-device flag array (a process may drive several GPUs; one process per GPU is the deployment, but a model on
+// cuda:1 in a process whose first launch was on cuda:0 must not inherit that device's "done")
 template <typename K>
-int set_lds_attr(K kernel, int lds, bool& done) {
+int set_lds_attr(K kernel, int lds, bool (&done_by_device)[RAJNI_MAX_DEVICES]) {
+  bool& done = done_by_device[rajni_current_device()];
   if (done) return RAJNI_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1163,7 +1049,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_tn_128x128(const GemmParams p
 
 template <int EPI, int ALOAD>
 int launch(GemmParams p, int kclass, hipStream_t s) {
-  static bool attr = false;
+  static bool attr[RAJNI_MAX_DEVICES] = {};
   p.tiles_n = (p.N + 127) / 128;
   p.total_tiles = p.tiles_n * ((p.M + 127) / 128);
   int rc = set_lds_attr(&gemm_f32_tn_128x128<EPI, ALOAD>, LDS_BYTES, attr);
@@ -1193,24 +1079,22 @@ __global__ void cls_pos_kernel(const T* cls, const T* pos, int pos_has_cls, void
 #define RAJNI_W8_WIDE_NS 2
 #endif
 #define RAJNI_W8_WIDE_NS_OR(w8) ((w8) ? RAJNI_W8_WIDE_NS : 2)
-int g_num_cus = 256;   // MI355X; the persistent GEMM launches one workgroup per CU
+// test / tuning hooks (include/rajni_hip_debug.h): process-global, unsynchronised - not for concurrent use
 int g_force_tiling = 0;  // 0 auto, 1 small (128x128x64, 2 stages), 4 wide 256x256x64, 5 mid 256x128x64 (tests)
-
 int g_nblk_bytes = RAJNI_GEMM_NBLK_BYTES;   // W bytes of one N block (0 = plain order, < 0 = forced block size: tuning)
-int g_rblk = 0;                              // row tiles per super-block of the tile order (0 = all rows; tuning hook)
 
 // column tiles per N block of the persistent tile order (see tile_mn).  Measured on the ViT-B shapes
 // (tools/nblk_bench.py): blocks of ~1.5 MiB of W help once every block spans at least two rounds of tiles
 // (QKV at 197 tokens 179 -> 161 us, FC1 254 -> 239 us); with fewer rounds W is not re-read often enough
 // to pay for reading X once per block, and K = 3072 (fc2) never pays.
-inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes) {
+inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes, int cus) {
   if (g_nblk_bytes < 0) return -g_nblk_bytes < tiles_n ? -g_nblk_bytes : tiles_n;
   if (g_nblk_bytes == 0) return tiles_n;
   const long per_tile = (long)bn * K * wbytes;
   const int fit = (int)(g_nblk_bytes / per_tile);
   if (fit < 1 || fit >= tiles_n) return tiles_n;
   const int blocks = (tiles_n + fit - 1) / fit;
-  const int rounds = tiles_n * tiles_m / 256;
+  const int rounds = tiles_n * tiles_m / cus;
   if (rounds < 2 * blocks) return tiles_n;
   return (tiles_n + blocks - 1) / blocks;
 }
@@ -1221,25 +1105,20 @@ inline int n_block(int tiles_n, int tiles_m, int bn, int K, int wbytes) {
 // 660 -> 537 us).  Cost model: full rounds of 256 tiles plus a partial round whose tiles run faster the emptier
 // the chip is (board power cap: DESIGN.md section 4 (10)); one 256x256 round = 1.83 256x128 rounds.  Not used for
 // K <= N (proj): there the epilogue dominates a tile and the ratio is larger (measured: 4 misses of 11).
-inline double eff_rounds(long tiles) {
-  const long full = tiles / 256;
-  const double frac = (double)tiles / 256.0 - (double)full;
+inline double eff_rounds(long tiles, int cus) {
+  const long full = tiles / cus;
+  const double frac = (double)tiles / (double)cus - (double)full;
   return (double)full + (frac > 0.0 ? 0.6 + 0.4 * frac : 0.0);
 }
-inline bool wide_wins_on_rounds(int M, int N) {
+inline bool wide_wins_on_rounds(int M, int N, int cus) {
   const long rows = (M + 255) / 256;
-  return 1.83 * eff_rounds(rows * ((N + 255) / 256)) < eff_rounds(rows * ((N + 127) / 128));
+  return 1.83 * eff_rounds(rows * ((N + 255) / 256), cus) < eff_rounds(rows * ((N + 127) / 128), cus);
 }
 
-int g_balance_grid = 0;   // tuning hook: 1 = as few workgroups as finish in the same number of rounds
-// persistent grid: one workgroup per CU; balanced: ceil(tiles / rounds) rounded up to whole XCD groups
-inline int stream_grid(int total_tiles) {
-  if (total_tiles <= g_num_cus) return total_tiles;
-  if (!g_balance_grid) return g_num_cus;
-  const int rounds = (total_tiles + g_num_cus - 1) / g_num_cus;
-  const int g = ((total_tiles + rounds - 1) / rounds + 7) & ~7;
-  return g < g_num_cus ? g : g_num_cus;
-}
+// persistent grid: one workgroup per CU of the device the launch goes to (hipDeviceProp_t::multiProcessorCount;
+// 256 on MI355X).  A grid balanced to whole rounds, as hipBLASLt picks for fc2, was measured: 0.7 % slower over
+// the 20 GEMM shapes of the schedule.
+inline int stream_grid(int total_tiles, int cus) { return total_tiles <= cus ? total_tiles : cus; }
 
 template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
@@ -1247,13 +1126,9 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
-  if ((mode == 4 || mode == 5 || mode == 6) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
-#ifdef RAJNI_GEMM_WIDE4
-  if (mode == 6 && (ALOAD != ALOAD_PLAIN || W8)) mode = 4;   // the 4-wave tiling is built for plain bf16 operands
-#else
-  if (mode == 6) mode = 4;   // experiment, not built by default (see the note at mode 6 below)
-#endif
-  if ((mode == 4 || mode == 6) && p.K < 192) mode = 1;   // the persistent streams need >= NS + 1 K steps
+  const int cus = rajni_num_cus();
+  if ((mode == 4 || mode == 5) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
+  if (mode == 4 && p.K < 192) mode = 1;                   // the persistent streams need >= NS + 1 K steps
   if (mode == 5 && p.K < 256) mode = 1;
   if (mode == 0) {
     // measured on ViT-B shapes (tools/gemm_bench.py, tools/proj_probe.py, profiles/):
@@ -1262,10 +1137,10 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     //   persistent 256x128 3-stage tiling is best (proj 125 us, fc2 284 us vs 127 / 310 for 128x128);
     //   small problems (head, tiny batches): 128x128.
     if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
-    else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N)) ? 4 : 5;
+    else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N, cus)) ? 4 : 5;
     else mode = 1;
   }
-  static bool attr[8] = {false, false, false, false, false, false, false, false};   // [2] small, [3] wide, [4] mid, [5] wide4, [6] [7] K<=N twins
+  static bool attr[5][RAJNI_MAX_DEVICES] = {};   // [0] small, [1] wide, [2] mid, [3] [4] their K<=N twins; per device
   // algorithmic bytes: X + W + output (+ the residual rows read), fp32 where the residual stream is fp32
   constexpr double ysz = (SF32 && (EPI == EPI_RESID || EPI == EPI_PATCH)) ? 4.0 : 2.0;
   constexpr double rsz = EPI == EPI_RESID ? (SF32 ? 4.0 : 2.0) : 0.0;
@@ -1275,55 +1150,36 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>, C::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, 1>, C::LDS_BYTES, attr[6])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
-    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);   // fp8 W: same blocks as bf16 (measured)
-    p.rblk = g_rblk;
-    const int grid = stream_grid(p.total_tiles);
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2, cus);   // fp8 W: same blocks as bf16 (measured)
+    const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     } else {
       hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     }
-#ifdef RAJNI_GEMM_WIDE4
-  // Experiment (-DRAJNI_GEMM_WIDE4, tiling 6): the same 256x256x64 tile on FOUR waves of 128x128 (NH = 2; 256
-  // VGPRs + 256 AGPRs, one wave per SIMD - the shape of hipBLASLt's MT256x256x64 kernel).  A third fewer LDS
-  // fragment bytes per MFMA, but with this schedule it is no faster: 8192^3 1253 vs 1211 TFLOP/s, QKV shape
-  // 909 vs 1143 (the epilogue of 256 outputs per lane is exposed at K = 768), K = 3072 1196 vs 1193.
-  } else if (mode == 6) {
-    if constexpr (ALOAD == ALOAD_PLAIN && !W8) {
-      using C = wide::Cfg<4, 2, false, 4>;
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 2, 8, 2, false, 2>, C::LDS_BYTES, attr[5])) != RAJNI_OK) return rc;
-      p.tiles_n = (p.N + 255) / 256;
-      p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
-      p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2);
-      p.rblk = g_rblk;
-      const int grid = stream_grid(p.total_tiles);
-      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 2, 8, 2, false, 2>), dim3(grid), dim3(256), C::LDS_BYTES, s, p);
-    }
-#endif
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>, C::LDS_BYTES, attr[2])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, 1>, C::LDS_BYTES, attr[7])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
-    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2);
-    p.rblk = g_rblk;
-    const int grid = stream_grid(p.total_tiles);
+    p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2, cus);
+    const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     } else {
       hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     }
   } else {
     constexpr int lds = small::LDS_BYTES;
-    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>, lds, attr[2])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>, lds, attr[0])) != RAJNI_OK) return rc;
     p.total_tiles = t128;
     hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>), dim3(t128), dim3(256), lds, s, p);
   }
@@ -1335,8 +1191,6 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
-extern "C" void rajni_debug_set_gemm_row_superblock(int row_tiles) { g_rblk = row_tiles; }
-extern "C" void rajni_debug_set_gemm_balanced_grid(int on) { g_balance_grid = on; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }
 

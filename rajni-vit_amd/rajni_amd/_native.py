@@ -75,8 +75,6 @@ _SIGS = {
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "rajni_debug_force_gemm_tiling": (None, [c_int]),
     "rajni_debug_set_gemm_nblock_bytes": (None, [c_int]),
-    "rajni_debug_set_gemm_row_superblock": (None, [c_int]),
-    "rajni_debug_set_gemm_balanced_grid": (None, [c_int]),
     "rajni_debug_force_attention": (None, [c_int]),
     "rajni_debug_set_gemm_stamps": (None, [c_void_p]),
     "rajni_patch_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -131,6 +129,27 @@ def check(rc: int, what: str = "") -> None:
 
 def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """Context manager that makes `device` the current HIP device for the native calls inside it.  The C ABI takes
+    raw pointers and a stream; kernel launches, hipFuncSetAttribute and the per-device CU count all go to the
+    CURRENT device, so a model on cuda:1 while cuda:0 is current must switch first.  Free when already current."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() == idx:
+        return _NO_GUARD
+    return torch.cuda.device(idx)
 
 
 def dtype_code(dt: torch.dtype) -> int:

@@ -87,8 +87,9 @@ def importance(qkv: torch.Tensor, num_heads: int, eps: float = 1e-6) -> torch.Te
     B, N, threeC = qkv.shape
     D = threeC // 3 // num_heads
     out = torch.empty((B, N), dtype=qkv.dtype, device=qkv.device)
-    nat.check(nat.lib().rajni_importance(qkv.data_ptr(), out.data_ptr(), B, N, num_heads, D, eps, _dt(qkv),
-                                         nat.stream_ptr(qkv.device)), "rajni_importance")
+    with nat.device_guard(qkv.device):
+        nat.check(nat.lib().rajni_importance(qkv.data_ptr(), out.data_ptr(), B, N, num_heads, D, eps, _dt(qkv),
+                                             nat.stream_ptr(qkv.device)), "rajni_importance")
     return out
 
 
@@ -98,8 +99,9 @@ def select_topk(scores: torch.Tensor, keep: int) -> Tuple[torch.Tensor, torch.Te
     B, N = scores.shape
     idx = torch.empty((B, keep + 1), dtype=torch.int32, device=scores.device)
     nxt = torch.empty((B, keep + 1), dtype=scores.dtype, device=scores.device)
-    nat.check(nat.lib().rajni_select_topk(scores.data_ptr(), B, N, keep, idx.data_ptr(), nxt.data_ptr(),
-                                          _dt(scores), nat.stream_ptr(scores.device)), "rajni_select_topk")
+    with nat.device_guard(scores.device):
+        nat.check(nat.lib().rajni_select_topk(scores.data_ptr(), B, N, keep, idx.data_ptr(), nxt.data_ptr(),
+                                              _dt(scores), nat.stream_ptr(scores.device)), "rajni_select_topk")
     return idx, nxt
 
 
@@ -111,9 +113,10 @@ def score_select(qkv: torch.Tensor, num_heads: int, keep: int, eps: float = 1e-6
     scores = torch.empty((B, N), dtype=qkv.dtype, device=qkv.device) if want_scores else None
     idx = torch.empty((B, keep + 1), dtype=torch.int32, device=qkv.device)
     nxt = torch.empty((B, keep + 1), dtype=qkv.dtype, device=qkv.device)
-    nat.check(nat.lib().rajni_score_select(qkv.data_ptr(), B, N, num_heads, D, eps, keep, nat.ptr(scores),
-                                           idx.data_ptr(), nxt.data_ptr(), _dt(qkv),
-                                           nat.stream_ptr(qkv.device)), "rajni_score_select")
+    with nat.device_guard(qkv.device):
+        nat.check(nat.lib().rajni_score_select(qkv.data_ptr(), B, N, num_heads, D, eps, keep, nat.ptr(scores),
+                                               idx.data_ptr(), nxt.data_ptr(), _dt(qkv),
+                                               nat.stream_ptr(qkv.device)), "rajni_score_select")
     return scores, idx, nxt
 
 
@@ -125,8 +128,9 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     B, N, E = src.shape
     K = idx.shape[1]
     out = torch.empty((B, K, E), dtype=src.dtype, device=src.device)
-    nat.check(nat.lib().rajni_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, N, K, E, _dt(src),
-                                          nat.stream_ptr(src.device)), "rajni_gather_rows")
+    with nat.device_guard(src.device):
+        nat.check(nat.lib().rajni_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, N, K, E, _dt(src),
+                                              nat.stream_ptr(src.device)), "rajni_gather_rows")
     return out
 
 
@@ -143,8 +147,9 @@ def attention(qkv: torch.Tensor, keep_idx: Optional[torch.Tensor], num_heads: in
     else:
         Np = N
     out = torch.empty((B, Np, Cc), dtype=qkv.dtype, device=qkv.device)
-    nat.check(nat.lib().rajni_attention(qkv.data_ptr(), nat.ptr(keep_idx), out.data_ptr(), B, N, Np, num_heads, D,
-                                        float(scale), _dt(qkv), nat.stream_ptr(qkv.device)), "rajni_attention")
+    with nat.device_guard(qkv.device):
+        nat.check(nat.lib().rajni_attention(qkv.data_ptr(), nat.ptr(keep_idx), out.data_ptr(), B, N, Np, num_heads, D,
+                                            float(scale), _dt(qkv), nat.stream_ptr(qkv.device)), "rajni_attention")
     return out
 
 
@@ -162,9 +167,10 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, row
         out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     else:
         out = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
-    nat.check(nat.lib().rajni_layernorm(x.data_ptr(), row_stride, w.data_ptr(), b.data_ptr(), out.data_ptr(), rows,
-                                        Cc, float(eps), nat.dtype_code(out_dtype), x_f32,
-                                        nat.stream_ptr(x.device)), "rajni_layernorm")
+    with nat.device_guard(x.device):
+        nat.check(nat.lib().rajni_layernorm(x.data_ptr(), row_stride, w.data_ptr(), b.data_ptr(), out.data_ptr(), rows,
+                                            Cc, float(eps), nat.dtype_code(out_dtype), x_f32,
+                                            nat.stream_ptr(x.device)), "rajni_layernorm")
     return out
 
 
@@ -197,7 +203,8 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
         if r_idx is not None:
             r_idx = r_idx.to(torch.int32).contiguous()
             a.r_idx, a.r_np, a.r_nsrc = r_idx.data_ptr(), r_idx.shape[1], resid.shape[1]
-    nat.check(nat.lib().rajni_linear(C.byref(a), nat.stream_ptr(x.device)), "rajni_linear")
+    with nat.device_guard(x.device):
+        nat.check(nat.lib().rajni_linear(C.byref(a), nat.stream_ptr(x.device)), "rajni_linear")
     y = out[:, :n_out] if ld != n_out else out
     return y.reshape(*x.shape[:-1], n_out) if ld == n_out else y
 
@@ -215,8 +222,9 @@ def patch_embed(images: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
         raise ValueError(f"patch_embed: weight must be packed with k_multiple=64 ([*, {kpad}]), got {tuple(w_packed.shape)}")
     nbytes = nat.lib().rajni_patch_embed_workspace_bytes(B, Cin, S, patch, _dt(images))   # 0: im2col fused into the loads
     ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device) if nbytes else None
-    nat.check(nat.lib().rajni_patch_embed(images.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), cls.data_ptr(),
-                                          pos.data_ptr(), int(pos_has_cls), x.data_ptr(), int(out_f32), B, Cin, S, patch,
-                                          embed_dim, _dt(images), nat.ptr(ws), nbytes, nat.stream_ptr(images.device)),
-              "rajni_patch_embed")
+    with nat.device_guard(images.device):
+        nat.check(nat.lib().rajni_patch_embed(images.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), cls.data_ptr(),
+                                              pos.data_ptr(), int(pos_has_cls), x.data_ptr(), int(out_f32), B, Cin, S, patch,
+                                              embed_dim, _dt(images), nat.ptr(ws), nbytes, nat.stream_ptr(images.device)),
+                  "rajni_patch_embed")
     return x

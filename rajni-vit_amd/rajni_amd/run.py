@@ -7,7 +7,8 @@ Same flags and printed report as the reference CLI; differences:
     generated on the device (no dataset or network exists in the build/bench images);
   * models come from timm when it is importable (`timm.create_model(name, pretrained=...)`),
     otherwise from the timm-shaped stand-in with seeded weights; `--weights file.safetensors|.pt`
-    loads a local timm-format state dict (torch.load with weights_only=True);
+    loads a local timm-format state dict (torch.load with weights_only=True); without `--weights` or
+    `--pretrained` the weights are random and the report says so (the reference always downloads pretrained ones);
   * under `torchrun --nproc-per-node N` every rank evaluates its shard of the batches and the
     counters are all-reduced (rajni_amd.evaluate_model).
 An ImageFolder loader is built only if torchvision is installed.
@@ -70,9 +71,41 @@ def create_base(args):
             sd = load_file(args.weights)
         else:
             sd = torch.load(args.weights, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict) and "state_dict" in sd and "cls_token" not in sd:
+            sd = sd["state_dict"]          # a timm training checkpoint wraps the weights
         model.load_state_dict(sd, strict=True)
         source += f" + {os.path.basename(args.weights)}"
+    elif not (args.pretrained and source == "timm"):
+        source += " [WARNING: random weights - accuracy is meaningless; pass --weights FILE or --pretrained]"
     return model.eval(), source
+
+
+class InputCast(torch.nn.Module):
+    """Stock base model behind a cast of the images to its dtype: an ImageFolder batch is fp32 and
+    `evaluate_model` only moves it to the device (eval.py:48), so a bf16 base would raise on its first conv.
+    (The RAJNI wrapper casts its own input.)"""
+
+    def __init__(self, model, dtype):
+        super().__init__()
+        self.model, self.dtype = model, dtype
+
+    def forward(self, x):
+        return self.model(x.to(self.dtype))
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Rank r of `world` sees samples r, r + world, ... - every sample exactly once over the ranks, no padding
+    (DistributedSampler repeats samples to even the shards out, which would count some images twice in the
+    all-reduced accuracy; evaluate_model's SUM of [correct, total] is exact for ragged shards)."""
+
+    def __init__(self, n, rank, world):
+        self.n, self.rank, self.world = n, rank, world
+
+    def __iter__(self):
+        return iter(range(self.rank, self.n, self.world))
+
+    def __len__(self):
+        return len(range(self.rank, self.n, self.world))
 
 
 class SyntheticLoader:
@@ -102,7 +135,7 @@ def build_loader(args, img_size, device, dtype, rank, world):
                                  transforms.CenterCrop(img_size), transforms.ToTensor(),
                                  transforms.Normalize((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))])
         ds = datasets.ImageFolder(args.data_path, transform=tf)
-        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=False) if world > 1 else None
+        sampler = ShardSampler(len(ds), rank, world) if world > 1 else None
         return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, sampler=sampler,
                                            num_workers=args.num_workers, pin_memory=True, drop_last=False)
     n = args.max_batches if args.max_batches is not None else 20
@@ -135,8 +168,8 @@ def main(argv=None):
     base_acc = base_thr = None
     if args.compare_base:
         say("Evaluating base model (stock PyTorch ops)...")
-        base_acc, base_thr = evaluate_model(base.to(dtype), loader, device=device, max_batches=args.max_batches,
-                                            warmup=args.warmup)
+        base_acc, base_thr = evaluate_model(InputCast(base.to(dtype), dtype), loader, device=device,
+                                            max_batches=args.max_batches, warmup=args.warmup)
         say(f"Base accuracy: {base_acc:.2f}%  throughput: {base_thr:.1f} img/s")
 
     schedule = load_schedule(args.schedule)

@@ -75,6 +75,9 @@ CONFIGS: Dict[str, ViTConfig] = {
     # tiny head_dim-64 model for fast parity tests (not a timm name)
     "vit_micro_patch16_64": ViTConfig(img_size=64, embed_dim=128, depth=4, num_heads=2,
                                       num_classes=10),
+    # the same with DeiT-3's LayerScale and no_embed_class pos-embed (N-1 rows): loader / B3 tests (not a timm name)
+    "deit3_micro_patch16_64": ViTConfig(img_size=64, embed_dim=128, depth=4, num_heads=2, num_classes=10,
+                                        layer_scale=1e-6, no_embed_class=True),
     # patch 14 (ViT-L/14, ViT-H/14, DINOv2): 3*14*14 = 588 input features, not whole 64-wide K steps
     "vit_micro_patch14_56": ViTConfig(img_size=56, patch_size=14, embed_dim=128, depth=4, num_heads=2,
                                       num_classes=10),

@@ -205,12 +205,34 @@ class RAJNIViTWrapper(nn.Module):
 
     def _all_params(self):
         """The base model's parameters.  Walking the module tree costs ~150 us per call - exposed latency in the
-        sync -> forward -> sync metric of evaluate_model - so the list is cached and re-walked every 64th
-        forward (a Parameter OBJECT replaced in between is picked up then; in-place changes, `.to()` and
-        `load_state_dict` are seen immediately through data_ptr / _version)."""
-        self._param_calls = getattr(self, "_param_calls", 0) + 1
-        if getattr(self, "_param_list", None) is None or self._param_calls % 64 == 0:
-            self._param_list = [p for p in self.m.parameters()]
+        sync -> forward -> sync metric of evaluate_model - so the walk is cached, and the cache is VALIDATED on every
+        call with plain dict lookups: every (parent, name, child module) and (owner, name, Parameter) slot recorded by
+        the walk must still hold the same object.  A replaced module (`model.head = nn.Linear(C, 10)`) or a re-assigned
+        `nn.Parameter` therefore re-walks and re-packs on the very next forward, like the reference, which reads the
+        live modules on every call; in-place changes, `.to()` and `load_state_dict` are seen through data_ptr / _version."""
+        slots = getattr(self, "_param_slots", None)
+        if slots is not None:
+            mods, pars = slots
+            ok = True
+            for parent, name, child in mods:
+                if parent._modules.get(name) is not child:
+                    ok = False
+                    break
+            if ok:
+                for owner, name, par in pars:
+                    if owner._parameters.get(name) is not par:
+                        ok = False
+                        break
+            if ok:
+                return self._param_list
+        mods, pars = [], []
+        for mod in self.m.modules():
+            for name, child in mod._modules.items():
+                mods.append((mod, name, child))
+            for name, par in mod._parameters.items():
+                pars.append((mod, name, par))
+        self._param_slots = (mods, pars)
+        self._param_list = [p for p in self.m.parameters()]
         return self._param_list
 
     def _pack_weights(self, device, dtype):
@@ -365,11 +387,12 @@ class RAJNIViTWrapper(nn.Module):
             x = x.to(dtype)
         x = x.contiguous()
         B, S = x.shape[0], x.shape[-1]
-        _, plan, keep_alive, _, counts = self._build_plan(B, S, x.device, dtype)
-        ld = plan.logits_ld
-        logits = torch.empty((B, ld), dtype=dtype, device=x.device)
-        nat.check(nat.lib().rajni_vit_forward(C.byref(plan), x.data_ptr(), logits.data_ptr(),
-                                              nat.stream_ptr(x.device)), "rajni_vit_forward")
+        with nat.device_guard(x.device):
+            _, plan, keep_alive, _, counts = self._build_plan(B, S, x.device, dtype)
+            ld = plan.logits_ld
+            logits = torch.empty((B, ld), dtype=dtype, device=x.device)
+            nat.check(nat.lib().rajni_vit_forward(C.byref(plan), x.data_ptr(), logits.data_ptr(),
+                                                  nat.stream_ptr(x.device)), "rajni_vit_forward")
         tc = keep_alive[1]
         self._last_stats = {"token_counts": [int(tc[i]) for i in range(plan.depth)]}   # model.py:68
         return logits[:, : plan.num_classes] if ld != plan.num_classes else logits

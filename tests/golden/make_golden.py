@@ -209,6 +209,65 @@ def evaluate_cases(ref):
     print("evaluate_cases written:", [(c["acc"], c["forwards"]) for c in cases])
 
 
+def agreement_case(ref, refw, name="base224_agree256", cfg_name="vit_base_patch16_224", schedule=README_SCHEDULE,
+                   batch=256, chunk=32, seed=2, std=0.04, bias_std=0.02):
+    """A fixture with RESOLUTION for "top-1 delta vs the reference wrapper" (eval.py:61-64 is an argmax count):
+    the reference's fp32 CPU forward of `batch` images of the BASELINE model dims and schedule - logits (fp32) and the
+    keep_idx of every stage (int16) - plus the reference's OWN bf16 CPU forward of the same images as the yardstick
+    (its argmax and its per-image max |dlogit| against the fp32 run).  Images are regenerated from the seed."""
+    cfg = ts.CONFIGS[cfg_name]
+    images = synth_images(cfg, batch, seed + 3000)
+    sched = {int(k): dict(v) for k, v in schedule.items()}
+    keep = {}
+    orig_forward = refw.RAJNIAttention.forward
+
+    def rec_forward(self, x, prev_scores=None):
+        out, keep_idx, nxt = orig_forward(self, x, prev_scores)
+        keep.setdefault(self._blk_index, []).append(keep_idx.numpy().astype(np.int16))
+        return out, keep_idx, nxt
+
+    def run(dtype, record):
+        model = ts.create_model(cfg, seed=seed, std=std, bias_std=bias_std, round_bf16=True)
+        wrapped = ref.RAJNIViTWrapper(model, {k: dict(v) for k, v in sched.items()}).to(dtype)
+        for i, blk in enumerate(wrapped.blocks):
+            if blk.has_pruner:
+                blk.attn._blk_index = i
+        if record:
+            refw.RAJNIAttention.forward = rec_forward
+        outs = []
+        try:
+            with torch.no_grad():
+                for c in range(0, batch, chunk):
+                    outs.append(wrapped(torch.from_numpy(images[c:c + chunk]).to(dtype)).float().numpy())
+                    print(f"  {name} {dtype}: {c + chunk}/{batch}", flush=True)
+        finally:
+            refw.RAJNIAttention.forward = orig_forward
+        return np.concatenate(outs), wrapped.get_last_stats()
+
+    logits, stats = run(torch.float32, True)
+    logits_bf16, _ = run(torch.bfloat16, False)
+    out = {"logits": logits, "token_counts": np.asarray(stats["token_counts"], np.int64),
+           "ref_bf16_argmax": logits_bf16.argmax(1).astype(np.int16),
+           "ref_bf16_max_abs_dlogit": np.abs(logits_bf16 - logits).max(1).astype(np.float32)}
+    for i, parts in keep.items():
+        out[f"blk{i}.keep_idx"] = np.concatenate(parts)
+    srt = np.sort(logits, axis=1)
+    meta = dict(name=name, cfg_name=cfg_name, schedule={str(k): v for k, v in schedule.items()}, batch=batch,
+                seed=seed, image_seed=seed + 3000, std=std, bias_std=bias_std, dtype="float32", boundary_gap={},
+                ref_bf16_top1_agree=int((logits_bf16.argmax(1) == logits.argmax(1)).sum()),
+                ref_bf16_max_abs_dlogit=float(np.abs(logits_bf16 - logits).max()),
+                logit_scale=float(np.abs(logits).max()),
+                median_top2_margin=float(np.median(srt[:, -1] - srt[:, -2])),
+                generator="tests/golden/make_golden.py agreement_case: reference RAJNIViTWrapper on CPU (fp32 run + its "
+                          "own bf16 run), torch " + torch.__version__)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"{name}: counts={stats['token_counts']} ref bf16 vs fp32: top-1 {meta['ref_bf16_top1_agree']}/{batch}, "
+          f"max|dlogit| {meta['ref_bf16_max_abs_dlogit']:.4f} (scale {meta['logit_scale']:.3f}), "
+          f"median top-2 margin {meta['median_top2_margin']:.4f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -232,6 +291,8 @@ def main():
         if only and c[0] not in only:
             continue
         run_case(ref, refw, *c)
+    if not only or "base224_agree256" in only:
+        agreement_case(ref, refw)
 
 
 if __name__ == "__main__":

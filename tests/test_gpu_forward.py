@@ -299,8 +299,9 @@ def test_large_384_aggressive_schedule_properties():
 
 def test_weight_changes_are_picked_up():
     """The wrapper packs the base model's weights once and caches them (and the parameter list): in-place
-    edits, load_state_dict and a replaced Parameter object must all invalidate the cache (Q4: the wrapper
-    shares parameters with the base model)."""
+    edits, load_state_dict, a replaced Parameter object and a replaced module must all invalidate the cache on the
+    NEXT forward (Q4: the wrapper shares parameters with the base model; the reference reads the live modules on
+    every call)."""
     cfg = ts.CONFIGS["vit_micro_patch16_64"]
     model = ts.create_model(cfg, seed=3, std=0.08, bias_std=0.02, round_bf16=True)
     w = rajni_amd.RAJNIViTWrapper(model, {1: {"keep_ratio": 0.7}}).to(DEV).to(torch.bfloat16).eval()
@@ -315,11 +316,27 @@ def test_weight_changes_are_picked_up():
     sd["head.bias"] = sd["head.bias"] - 1.0
     model.load_state_dict(sd)                                       # copy_ into the same storage
     assert torch.allclose(w(x).float(), y0, atol=2e-2)
-    model.head.bias = torch.nn.Parameter(model.head.bias.detach() + 2.0)   # a NEW Parameter object
-    y2 = None
-    for _ in range(70):                                             # the parameter list is re-walked every 64th forward
-        y2 = w(x).float()
-    assert torch.allclose(y2, y0 + 2.0, atol=3e-2)
+    model.head.bias = torch.nn.Parameter(model.head.bias.detach() + 2.0)   # a NEW Parameter object ...
+    assert torch.allclose(w(x).float(), y0 + 2.0, atol=3e-2)              # ... is seen on the very next forward
+    # a replaced MODULE (the classic fine-tuning edit) too: new class count, new weights, next forward
+    new_head = torch.nn.Linear(cfg.embed_dim, 7).to(DEV).to(torch.bfloat16)
+    model.head = new_head
+    y3 = w(x).float()
+    assert y3.shape == (2, 7)
+    feats = model.head.weight.float()
+    with torch.no_grad():
+        new_head.bias.add_(1.0)
+    assert torch.allclose(w(x).float(), y3 + 1.0, atol=2e-2)
+    del feats
+    # and a replaced block-level Linear
+    blk = model.blocks[0]
+    old_fc2 = blk.mlp.fc2
+    blk.mlp.fc2 = torch.nn.Linear(old_fc2.in_features, old_fc2.out_features).to(DEV).to(torch.bfloat16)
+    y4 = w(x).float()
+    assert not torch.allclose(y4, y3 + 1.0, atol=1e-3)
+    blk.mlp.fc2 = old_fc2
+    assert torch.equal(w(x).float(), w(x).float())
+    assert torch.allclose(w(x).float(), y3 + 1.0, atol=2e-2)
 
 
 @pytest.mark.parametrize("name,dtype,fp8", [("micro_fp32", torch.bfloat16, False), ("base224_fp32", torch.bfloat16, False),

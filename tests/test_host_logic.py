@@ -34,9 +34,13 @@ def test_public_names_match_reference_surface():
 
 
 def test_library_exports_every_declared_symbol():
-    """Every `rajni_*(` prototype in include/rajni_hip.h resolves in librajni_hip.so (no compute)."""
+    """Every `rajni_*(` prototype in include/rajni_hip.h (the boundary) and include/rajni_hip_debug.h (test hooks,
+    kept out of the boundary header) resolves in librajni_hip.so (no compute)."""
     with open(os.path.join(ROOT, "include", "rajni_hip.h")) as f:
         header = f.read()
+    assert "rajni_debug_" not in header, "debug hooks belong in rajni_hip_debug.h"
+    with open(os.path.join(ROOT, "include", "rajni_hip_debug.h")) as f:
+        header += f.read()
     declared = set(re.findall(r"\b(rajni_[a-z0-9_]+)\s*\(", header))
     declared -= {"rajni_stream_t"}
     assert len(declared) >= 15
@@ -199,6 +203,132 @@ def test_cli_flags_match_reference_and_schedule_loader(tmp_path):
     f.write_text('{"3": {"keep_ratio": 0.95, "update": false}, "4": {"keep_ratio": 0.95}}')
     assert run.load_schedule(str(f)) == {3: {"keep_ratio": 0.95, "update": False}, 4: {"keep_ratio": 0.95}}
     assert run.load_schedule(None) == run.README_SCHEDULE
+
+
+def _timm_named_micro_state_dict(cfg_name, seed):
+    """A timm-NAMED fp32 state dict with non-default values everywhere (incl. DeiT-3's ls{1,2}.gamma and an
+    N-1-row pos_embed when the config is no_embed_class)."""
+    cfg = ts.CONFIGS[cfg_name]
+    sd = ts.synth_state_dict(cfg, seed=seed, std=0.08, bias_std=0.02)
+    return cfg, {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("cfg_name", ["vit_micro_patch16_64", "deit3_micro_patch16_64"])
+@pytest.mark.parametrize("fmt", ["safetensors", "pt", "pt_wrapped"])
+def test_weights_loader_round_trip(tmp_path, cfg_name, fmt):
+    """`--weights FILE` (the offline replacement of the reference's `timm.create_model(pretrained=True)`,
+    rajni/run.py:89-92): a timm-named state dict written as .safetensors / .pt (also wrapped as a training
+    checkpoint {"state_dict": ...}) loads through run.create_base into a model whose state dict is bit-identical -
+    including LayerScale gammas and the N-1-row pos_embed of a no_embed_class model (SURVEY B3)."""
+    from rajni_amd import run
+    cfg, sd = _timm_named_micro_state_dict(cfg_name, seed=11)
+    if cfg.layer_scale:
+        assert any(k.endswith("ls1.gamma") for k in sd) and sd["pos_embed"].shape[1] == cfg.num_patches
+    if fmt == "safetensors":
+        from safetensors.torch import save_file
+        path = tmp_path / "w.safetensors"
+        save_file(sd, str(path))
+    else:
+        path = tmp_path / "w.pt"
+        torch.save({"state_dict": sd, "epoch": 3} if fmt == "pt_wrapped" else sd, str(path))
+    args = run.get_args(["--model", cfg_name, "--weights", str(path), "--seed", "5"])
+    model, source = run.create_base(args)
+    assert os.path.basename(str(path)) in source and "WARNING" not in source
+    got = model.state_dict()
+    assert set(got) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    # a file that does not fit the model is an error, not a partial load (strict=True)
+    bad = dict(sd)
+    bad.pop("head.bias")
+    torch.save(bad, str(tmp_path / "bad.pt"))
+    with pytest.raises(RuntimeError, match="head.bias"):
+        run.create_base(run.get_args(["--model", cfg_name, "--weights", str(tmp_path / "bad.pt")]))
+    # without --weights / --pretrained the report says the weights are random
+    _, src2 = run.create_base(run.get_args(["--model", cfg_name]))
+    assert "WARNING: random weights" in src2
+
+
+def test_shard_sampler_covers_every_sample_once():
+    from rajni_amd.run import ShardSampler
+    for n, world in [(10, 4), (7, 2), (3, 8), (0, 2)]:
+        seen = sorted(i for r in range(world) for i in ShardSampler(n, r, world))
+        assert seen == list(range(n))
+        assert sum(len(ShardSampler(n, r, world)) for r in range(world)) == n
+
+
+def test_param_cache_sees_replaced_parameters_and_modules():
+    """RAJNIViTWrapper caches the walk over the base model's parameters and validates the cache on EVERY forward
+    (ADVICE r1: a swapped head / re-assigned Parameter used to be invisible for up to 63 forwards)."""
+    m = ts.create_model("vit_micro_patch16_64")
+    w = rajni_amd.RAJNIViTWrapper(m, {1: {"keep_ratio": 0.5}})
+    a = w._all_params()
+    assert w._all_params() is a                                   # unchanged model: the cached list
+    m.head.bias = torch.nn.Parameter(m.head.bias.detach() + 1)     # re-assigned Parameter object
+    b = w._all_params()
+    assert b is not a and any(p is m.head.bias for p in b)
+    m.head = torch.nn.Linear(m.embed_dim, 7)                       # replaced module
+    c = w._all_params()
+    assert c is not b and any(p is m.head.weight for p in c)
+    m.blocks[0].mlp.fc2 = torch.nn.Linear(m.blocks[0].mlp.fc2.in_features, m.embed_dim)
+    d = w._all_params()
+    assert d is not c and any(p is m.blocks[0].mlp.fc2.weight for p in d)
+    assert w._all_params() is d
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rajni_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_without_launcher_spawns_n_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) must START N ranks - never run one rank and
+    label it N (VERDICT r1 weak #1) - before touching a GPU, relay rank 0's line and return the launcher's status."""
+    import subprocess
+    bench = _load_bench()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    monkeypatch.setattr(bench, "worker", lambda args: pytest.fail("the parent must not run the benchmark itself"))
+    calls = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            calls["cmd"], calls["env"] = cmd, env
+            self.stdout = iter(["rank chatter\n", json.dumps({"metric": "images/sec", "n_gpus": 4, "ranks_seen": 4}) + "\n"])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    rc = bench.main(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert rc == 0
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and json.loads(out[0])["ranks_seen"] == 4          # ONE JSON line, relayed
+    assert not torch.cuda.is_initialized()                                   # the parent stayed off the GPU
+
+
+def test_bench_refuses_fewer_devices_than_ranks(monkeypatch, capsys):
+    """Fewer visible devices than --gpus: exit non-zero, never fall back to a smaller job."""
+    import subprocess
+    bench = _load_bench()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RAJNI_BENCH_ONE_DEVICE", raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: pytest.fail("must not launch"))
+    assert bench.main(["--gpus", "8"]) == 3
+    assert "needs 8 visible" in capsys.readouterr().err
+    # a launcher-provided world size that disagrees with --gpus is refused too
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="refusing"):
+        bench.main(["--gpus", "8"])
 
 
 def test_fp8_row_quantiser_properties():

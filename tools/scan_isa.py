@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def kernel_id(mangled):
-    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, NH, TAG> -> tuple of ints"""
+    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, TAG> -> tuple of ints"""
     m = re.search(r"gemm_bf16_tn_streamI(.*?)EEv", mangled)
     return tuple(int(x[2:]) for x in re.findall(r"L[ib]\d+", m.group(1)))
 
@@ -25,7 +25,7 @@ def kernel_id(mangled):
 def dispatched(k):
     """instantiations launch_gemm picks without a test hook: everything except the 256x256 tiling with the
     fused patch loader (a patch embed wider than 1536 channels has K = 3*14*14, not a multiple of 64)."""
-    epi, aload, sf32, wm, wn, mi, ns, w8, nh, tag = k
+    epi, aload, sf32, wm, wn, mi, ns, w8, tag = k
     return not ((wm, wn, mi, ns) == (2, 4, 8, 2) and aload == 1)
 
 
