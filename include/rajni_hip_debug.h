@@ -21,6 +21,10 @@ void rajni_debug_force_gemm_tiling(int mode);
  * order; -k = blocks of k column tiles regardless of size.  Results are bit-identical for every value (tested). */
 void rajni_debug_set_gemm_nblock_bytes(int bytes);
 
+/* score+select: 1 = read K and V in two passes with vbar reusing the logits' LDS region (what N = 577 x 16 heads
+ * needs) even when the one-pass layout fits; 0 = default.  Scores are bit-identical either way (tested). */
+void rajni_debug_force_score_two_pass(int on);
+
 /* diagnostic builds (-DRAJNI_GEMM_STAMPS / -DRAJNI_ATTN_STAMPS / -DRAJNI_SS_STAMPS) only: device buffer receiving
  * 4 x uint64 s_memtime stamps per workgroup; NULL disables */
 void rajni_debug_set_gemm_stamps(void* buf);

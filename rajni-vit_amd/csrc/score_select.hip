@@ -51,15 +51,20 @@ __device__ __forceinline__ float group_sum(float v, int width) {
   return v;
 }
 
-template <bool COMPUTE, typename T>
+// MERGED: logits and vbar have LDS regions of their own and K and V rows are read in ONE pass (a token's K and V
+// thirds are 3072 contiguous bytes of its 4608-byte qkv row, and no V load has to wait for the softmax statistics);
+// otherwise (N = 577 with 16 heads: 185 KiB would be needed) vbar reuses the logits' region after the statistics.
+template <bool COMPUTE, typename T, bool MERGED>
 __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
   const int N = a.N, H = a.H, D = a.D, C = H * D;
-  const int region_sz = (H * N > N * D) ? H * N : N * D;
+  const int lg_sz = (H * N + 3) & ~3;
+  const int region_sz = MERGED ? lg_sz + N * D : ((H * N > N * D) ? H * N : N * D);
   float* qcls = sm;                    // [C]
-  float* region = qcls + C;            // logits [H][N]  then  vbar [N][D]
+  float* region = qcls + C;            // logits [H][N]  (then / followed by)  vbar [N][D]
+  float* vbar = MERGED ? region + lg_sz : region;
   float* acls = region + region_sz;    // [N]
   float* sc = acls + N;                // vnorm [N] then scores [N]
   float* hstat = sc + N;               // [2H]
@@ -92,78 +97,59 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     // chunks of a head sit in LP consecutive lanes and are summed with DPP adds (ds_bpermute shuffles and an
     // integer division per item made this loop 34 of the kernel's 60 us).  U loads in flight per thread.
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
-    if (!pow2) {
-      for (int item = tid; item < N * H; item += SS_THREADS) {   // consecutive lanes = consecutive heads of a row
-        const int n = item / H, h = item - n * H;
-        const T* kp = base + (long)n * 3 * C + C + h * D;
-        float dot = 0.f;
-        for (int c = 0; c < LP; ++c) {
-          float kf[8];
-          load8<T>(kp + c * 8, kf);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) dot = fmaf(kf[j], qcls[h * D + c * 8 + j], dot);
-        }
-        region[h * N + n] = dot * inv_sqrt_d;
-      }
-    } else {
-      constexpr int U = RAJNI_SS_KU;
-      const int CP = C >> 3;
-      const int dn = SS_THREADS / CP, dc = SS_THREADS - dn * CP;   // item index += SS_THREADS
-      int n = tid / CP, c = tid - n * CP;
-      while (n < N) {
-        float kf[U][8];
-        int nn[U], cc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          nn[u] = n; cc[u] = c;
-          if (n < N) load8<T>(base + (long)n * 3 * C + C + c * 8, kf[u]);
-          n += dn; c += dc;
-          if (c >= CP) { c -= CP; ++n; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (nn[u] < N) {
-            const float4 q0 = *reinterpret_cast<const float4*>(qcls + cc[u] * 8);
-            const float4 q1 = *reinterpret_cast<const float4*>(qcls + cc[u] * 8 + 4);
-            float dot = kf[u][0] * q0.x;
-            dot = fmaf(kf[u][1], q0.y, dot); dot = fmaf(kf[u][2], q0.z, dot); dot = fmaf(kf[u][3], q0.w, dot);
-            dot = fmaf(kf[u][4], q1.x, dot); dot = fmaf(kf[u][5], q1.y, dot); dot = fmaf(kf[u][6], q1.z, dot);
-            dot = fmaf(kf[u][7], q1.w, dot);
-            dot = group_sum(dot, LP);
-            if ((cc[u] & (LP - 1)) == 0) region[(cc[u] / LP) * N + nn[u]] = dot * inv_sqrt_d;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    SS_STAMP(1);
-
-    // ---- per-head softmax statistics over ALL N tokens (importance.py:20)
-    for (int h = wave; h < H; h += SS_THREADS / 64) {
-      float mx = -INFINITY;
-      for (int n = lane; n < N; n += 64) mx = fmaxf(mx, region[h * N + n]);
-      mx = wave_max(mx);
-      float se = 0.f;
-      for (int n = lane; n < N; n += 64) se += __expf(region[h * N + n] - mx);
-      se = wave_sum(se);
-      if (lane == 0) { hstat[h] = mx; hstat[H + h] = se; }
-    }
-    __syncthreads();
-    // ---- A_cls[n] = mean_h softmax_h[n]   (importance.py:21)
-    for (int n = tid; n < N; n += SS_THREADS) {
-      float s = 0.f;
-      for (int h = 0; h < H; ++h) s += __expf(region[h * N + n] - hstat[h]) / hstat[H + h];
-      acls[n] = s / (float)H;
-    }
-    __syncthreads();  // logits are dead: region becomes vbar
-    SS_STAMP(2);
-
-    // ---- vbar[n][:] = mean_h v[n,h,:]   (importance.py:24)
     const float inv_h = 1.0f / (float)H;
-    for (int n = grp < ngrp ? grp : N; n < N; n += ngrp) {
+    constexpr int U = RAJNI_SS_KU;
+    const int CP = C >> 3;
+    const int dn = SS_THREADS / CP, dc = SS_THREADS - dn * CP;   // K item index += SS_THREADS
+    // one K chunk: dot with the CLS query chunk, summed over the head's LP lanes, lane 0 of the group stores
+    auto k_item = [&](const float (&kf)[8], int n, int c) {
+      const float4 q0 = *reinterpret_cast<const float4*>(qcls + c * 8);
+      const float4 q1 = *reinterpret_cast<const float4*>(qcls + c * 8 + 4);
+      float dot = kf[0] * q0.x;
+      dot = fmaf(kf[1], q0.y, dot); dot = fmaf(kf[2], q0.z, dot); dot = fmaf(kf[3], q0.w, dot);
+      dot = fmaf(kf[4], q1.x, dot); dot = fmaf(kf[5], q1.y, dot); dot = fmaf(kf[6], q1.z, dot);
+      dot = fmaf(kf[7], q1.w, dot);
+      dot = group_sum(dot, LP);
+      if ((c & (LP - 1)) == 0) region[(c / LP) * N + n] = dot * inv_sqrt_d;
+    };
+    auto k_pass = [&]() {
+      if (!pow2) {
+        for (int item = tid; item < N * H; item += SS_THREADS) {   // consecutive lanes = consecutive heads of a row
+          const int n = item / H, h = item - n * H;
+          const T* kp = base + (long)n * 3 * C + C + h * D;
+          float dot = 0.f;
+          for (int c = 0; c < LP; ++c) {
+            float kf[8];
+            load8<T>(kp + c * 8, kf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot = fmaf(kf[j], qcls[h * D + c * 8 + j], dot);
+          }
+          region[h * N + n] = dot * inv_sqrt_d;
+        }
+      } else {
+        int n = tid / CP, c = tid - n * CP;
+        while (n < N) {
+          float kf[U][8];
+          int nn[U], cc[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            nn[u] = n; cc[u] = c;
+            if (n < N) load8<T>(base + (long)n * 3 * C + C + c * 8, kf[u]);
+            n += dn; c += dc;
+            if (c >= CP) { c -= CP; ++n; }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (nn[u] < N) k_item(kf[u], nn[u], cc[u]);
+        }
+      }
+    };
+    // ---- vbar[n][:] = mean_h v[n,h,:]   (importance.py:24): thread (token n, 16-byte slice `sub` of the head dim),
+    //      12 head rows in flight, summed in head order (fixed tree)
+    auto v_item = [&](int n) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const T* vp = base + (long)n * 3 * C + 2 * C + sub * 8;
-      for (int h0 = 0; h0 < H; h0 += 12) {     // 12 head rows in flight; summed in head order (fixed tree)
+      for (int h0 = 0; h0 < H; h0 += 12) {
         float vf[12][8];
 #pragma unroll
         for (int u = 0; u < 12; ++u)
@@ -175,17 +161,103 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
             for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
           }
       }
-      float* dst = region + n * D + sub * 8;
+      float* dst = vbar + n * D + sub * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) dst[j] = acc[j] * inv_h;
+    };
+    auto v_pass = [&]() {
+      for (int n = grp < ngrp ? grp : N; n < N; n += ngrp) v_item(n);
+    };
+    // ---- per-head softmax statistics over ALL N tokens (importance.py:20), then A_cls[n] = mean_h softmax_h[n]
+    //      (importance.py:21)
+    auto softmax_stats = [&]() {
+      for (int h = wave; h < H; h += SS_THREADS / 64) {
+        float mx = -INFINITY;
+        for (int n = lane; n < N; n += 64) mx = fmaxf(mx, region[h * N + n]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int n = lane; n < N; n += 64) se += __expf(region[h * N + n] - mx);
+        se = wave_sum(se);
+        if (lane == 0) { hstat[h] = mx; hstat[H + h] = se; }
+      }
+      __syncthreads();
+      for (int n = tid; n < N; n += SS_THREADS) {
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += __expf(region[h * N + n] - hstat[h]) / hstat[H + h];
+        acls[n] = s / (float)H;
+      }
+    };
+
+    if (MERGED && pow2) {
+      // ONE pass over the K and V thirds: per iteration a thread has U K chunks and the H head rows of one V
+      // item in flight (every result is the same fixed-order sum as in the two-pass form: bit-identical scores)
+      int n = tid / CP, c = tid - n * CP;
+      int nv = grp < ngrp ? grp : N;
+      while (n < N || nv < N) {
+        float kf[U][8];
+        int nn[U], cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          nn[u] = n; cc[u] = c;
+          if (n < N) load8<T>(base + (long)n * 3 * C + C + c * 8, kf[u]);
+          n += dn; c += dc;
+          if (c >= CP) { c -= CP; ++n; }
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool vdo = nv < N;
+        const T* vp = base + (long)(vdo ? nv : 0) * 3 * C + 2 * C + sub * 8;
+        float vf[12][8];
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+          if (vdo && u < H) load8<T>(vp + u * D, vf[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (nn[u] < N) k_item(kf[u], nn[u], cc[u]);
+        if (vdo) {
+#pragma unroll
+          for (int u = 0; u < 12; ++u)
+            if (u < H) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
+            }
+          for (int h0 = 12; h0 < H; h0 += 12) {       // more than 12 heads: further rounds of 12
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+              if (h0 + u < H) load8<T>(vp + (h0 + u) * D, vf[u]);
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+              if (h0 + u < H) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
+              }
+          }
+          float* dst = vbar + nv * D + sub * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dst[j] = acc[j] * inv_h;
+          nv += ngrp;
+        }
+      }
+      __syncthreads();
+      SS_STAMP(1);
+      softmax_stats();
+      __syncthreads();
+      SS_STAMP(2);
+    } else {
+      k_pass();
+      __syncthreads();
+      SS_STAMP(1);
+      softmax_stats();
+      __syncthreads();  // logits are dead: region becomes vbar (two-pass layout)
+      SS_STAMP(2);
+      v_pass();
+      __syncthreads();
     }
-    __syncthreads();
     SS_STAMP(3);
     // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
     {
       const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;   // threads past nparts * D idle
       float s = 0.f;
-      for (int n = prt < nparts ? prt : N; n < N; n += nparts) s += region[n * D + d];
+      for (int n = prt < nparts ? prt : N; n < N; n += nparts) s += vbar[n * D + d];
       if (prt < nparts) part[prt * D + d] = s;
       __syncthreads();
       if (tid < D) {
@@ -200,14 +272,14 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
       for (int n = tid; n < N; n += SS_THREADS) {
         float ss = 0.f;
         for (int d = 0; d < D; ++d) {
-          const float dlt = region[n * D + d] - mean[d];
+          const float dlt = vbar[n * D + d] - mean[d];
           ss = fmaf(dlt, dlt, ss);
         }
         sc[n] = sqrtf(ss);
       }
     } else
     for (int n = grp; n < N; n += ngrp) {
-      const float* src = region + n * D + sub * 8;
+      const float* src = vbar + n * D + sub * 8;
       const float* mp = mean + sub * 8;
       float ss = 0.f;
 #pragma unroll
@@ -311,13 +383,18 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   SS_STAMP(6);
 }
 
-size_t ss_lds_bytes(int N, int H, int D) {
+size_t ss_lds_bytes(int N, int H, int D, bool merged) {
   const size_t C = (size_t)H * D;
-  const size_t region = (size_t)((H * N > N * D) ? H * N : N * D);
+  const size_t region = merged ? (size_t)((H * N + 3) & ~3) + (size_t)N * D
+                               : (size_t)((H * N > N * D) ? H * N : N * D);
   return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_THREADS + D + 16 + 8) * sizeof(float);
 }
 
+int g_ss_force_two_pass = 0;   // test hook (rajni_hip_debug.h): 1 = the two-pass layout even when the merged one fits
+
 }  // namespace
+
+extern "C" void rajni_debug_force_score_two_pass(int on) { g_ss_force_two_pass = on; }
 
 // qkv != null: compute scores (and select when keep > 0); qkv == null: select from scores_in.
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
@@ -333,26 +410,28 @@ int launch_score_select(const void* qkv, const void* scores_in, int B, int N, in
   a.scores_out = scores_out; a.keep_idx = keep_idx; a.next_scores = next_scores;
   a.stamps = rajni_g_stamps;
   size_t lds;
+  bool merged = false;
   if (qkv != nullptr) {
     RAJNI_REQUIRE(D >= 8 && D <= 128 && D % 8 == 0, RAJNI_ERR_UNSUPPORTED,
                   "importance: head dim %d not supported (multiples of 8 up to 128)", D);
     RAJNI_REQUIRE(H > 0, RAJNI_ERR_INVALID, "importance: H must be positive");
     a.qkv = qkv; a.H = H; a.D = D;
-    lds = ss_lds_bytes(N, H, D);
+    merged = ss_lds_bytes(N, H, D, true) <= 160 * 1024 && g_ss_force_two_pass == 0;   // else vbar reuses the logits' region
+    lds = ss_lds_bytes(N, H, D, merged);
   } else {
     RAJNI_REQUIRE(scores_in != nullptr, RAJNI_ERR_INVALID, "select: scores is null");
     a.scores_in = scores_in; a.H = 1; a.D = 32;
-    lds = ss_lds_bytes(N, 1, 32);
+    lds = ss_lds_bytes(N, 1, 32, false);
   }
   RAJNI_REQUIRE(lds <= 160 * 1024, RAJNI_ERR_UNSUPPORTED,
                 "score/select: N=%d H=%d D=%d needs %zu B of LDS (> 160 KiB)", N, H, D, lds);
   const bool f32 = dtype == RAJNI_F32;
-  const void* fn = qkv ? (f32 ? reinterpret_cast<const void*>(&score_select_kernel<true, float>)
-                              : reinterpret_cast<const void*>(&score_select_kernel<true, bf16_t>))
-                       : (f32 ? reinterpret_cast<const void*>(&score_select_kernel<false, float>)
-                              : reinterpret_cast<const void*>(&score_select_kernel<false, bf16_t>));
+  typedef void (*kern_t)(const ScoreArgs);
+  const kern_t kern = qkv ? (merged ? (f32 ? &score_select_kernel<true, float, true> : &score_select_kernel<true, bf16_t, true>)
+                                    : (f32 ? &score_select_kernel<true, float, false> : &score_select_kernel<true, bf16_t, false>))
+                          : (f32 ? &score_select_kernel<false, float, false> : &score_select_kernel<false, bf16_t, false>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       rajni_set_error("hipFuncSetAttribute(score_select, %zu): %s", lds, hipGetErrorString(e));
       return RAJNI_ERR_LAUNCH;
@@ -361,13 +440,7 @@ int launch_score_select(const void* qkv, const void* scores_in, int B, int N, in
   const double es = f32 ? 4.0 : 2.0;
   const double bytes = qkv ? (2.0 * N * H * D + H * D) * es * B + 4.0 * N * B : 6.0 * N * B;
   ProfScope prof(qkv ? (keep > 0 ? KC_SCORE_SELECT : KC_IMPORTANCE) : KC_SELECT, s, 0.0, bytes);
-  if (qkv) {
-    if (f32) hipLaunchKernelGGL((score_select_kernel<true, float>), dim3(B), dim3(SS_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((score_select_kernel<true, bf16_t>), dim3(B), dim3(SS_THREADS), lds, s, a);
-  } else {
-    if (f32) hipLaunchKernelGGL((score_select_kernel<false, float>), dim3(B), dim3(SS_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((score_select_kernel<false, bf16_t>), dim3(B), dim3(SS_THREADS), lds, s, a);
-  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(SS_THREADS), lds, s, a);
   RAJNI_CHECK_LAUNCH("score_select_kernel");
   return RAJNI_OK;
 }

@@ -76,6 +76,7 @@ _SIGS = {
     "rajni_debug_force_gemm_tiling": (None, [c_int]),
     "rajni_debug_set_gemm_nblock_bytes": (None, [c_int]),
     "rajni_debug_force_attention": (None, [c_int]),
+    "rajni_debug_force_score_two_pass": (None, [c_int]),
     "rajni_debug_set_gemm_stamps": (None, [c_void_p]),
     "rajni_patch_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rajni_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,

@@ -264,6 +264,27 @@ def test_score_select_fused(B, N, H):
     assert torch.equal(s2, scores)
 
 
+@pytest.mark.parametrize("B,N,H,D,dt", [(5, 197, 12, 64, "bf16"), (3, 404, 16, 64, "bf16"), (2, 173, 6, 64, "f32"),
+                                         (4, 87, 4, 32, "bf16"), (2, 152, 2, 128, "bf16"), (3, 61, 4, 80, "bf16")])
+def test_score_select_one_pass_equals_two_pass(B, N, H, D, dt):
+    """The kernel reads K and V in ONE pass when logits and vbar both fit in LDS, in two passes otherwise (vbar
+    reusing the logits' region; N = 577 x 16 heads).  Every score is the same fixed-order fp32 sum in both
+    layouts: scores, selections and carried scores must be BIT-identical."""
+    rng = np.random.default_rng(N + H)
+    qkv = rng.standard_normal((B, N, 3 * H * D), dtype=np.float32)
+    t = dev_bf16(bf16_round_np(qkv)) if dt == "bf16" else torch.from_numpy(qkv).to(DEV)
+    keep = orc.keep_count(0.8, N)
+    try:
+        nat.lib().rajni_debug_force_score_two_pass(1)
+        s2, i2, n2 = ops.score_select(t, H, keep)
+        only2 = ops.importance(t, H)
+    finally:
+        nat.lib().rajni_debug_force_score_two_pass(0)
+    s1, i1, n1 = ops.score_select(t, H, keep)
+    assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(n1, n2)
+    assert torch.equal(ops.importance(t, H), only2) and torch.equal(only2, s1)
+
+
 # ---------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------

@@ -14,6 +14,10 @@ def t(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
+from rajni_amd import _native as nat
+two = "--two-pass" in sys.argv
+nat.lib().rajni_debug_force_score_two_pass(1 if two else 0)
+print("layout:", "two-pass (forced)" if two else "one-pass where it fits")
 for (B, N, H, keep) in [(256, 197, 12, 172), (256, 173, 12, 151), (256, 152, 12, 120), (256, 121, 12, 86), (64, 577, 16, 403)]:
     qkv = torch.randn(B, N, 3 * H * 64, device="cuda").to(torch.bfloat16)
     sc = ops.importance(qkv, H)
