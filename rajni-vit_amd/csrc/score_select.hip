@@ -1,7 +1,7 @@
 // RAJNI importance score + per-image top-k selection + order-preserving compaction
 // (SURVEY k3-k9,k14; reference importance.py:4-34, attention.py:31-39,58) in ONE launch per stage.
 //
-// One 512-thread workgroup per image.  HBM traffic = the K and V thirds of qkv, read once with
+// One 1024-thread workgroup per image (16 waves: the two read passes are bound by loads in flight per CU).  HBM traffic = the K and V thirds of qkv, read once with
 // 16-byte loads; logits, head-mean V, norms and scores live in LDS; selection is a rank count
 // (N <= 577 scores, broadcast LDS reads) followed by wave ballot + popcount prefix compaction, which
 // yields the ascending index list directly (the reference's topk -> sort).
@@ -14,9 +14,18 @@
 
 namespace {
 
-constexpr int SS_THREADS = 512;
+#ifndef RAJNI_SS_THREADS
+#define RAJNI_SS_THREADS 1024
+#endif
+constexpr int SS_THREADS = RAJNI_SS_THREADS;
 #ifndef RAJNI_SS_KU
 #define RAJNI_SS_KU 8   // K-pass chunks in flight per lane
+#endif
+#ifndef RAJNI_SS_KUM
+#define RAJNI_SS_KUM 4  // ... in the one-pass form, next to RAJNI_SS_VUM V head rows of the lane's V item
+#endif
+#ifndef RAJNI_SS_VUM
+#define RAJNI_SS_VUM 6
 #endif
 
 struct ScoreArgs {          // T = activation dtype (bf16_t or float)
@@ -61,7 +70,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   const int b = blockIdx.x;
   const int N = a.N, H = a.H, D = a.D, C = H * D;
   const int lg_sz = (H * N + 3) & ~3;
-  const int region_sz = MERGED ? lg_sz + N * D : ((H * N > N * D) ? H * N : N * D);
+  const int region_sz = MERGED ? lg_sz + N * D : (((H * N > N * D) ? H * N : N * D) + 3) & ~3;
   float* qcls = sm;                    // [C]
   float* region = qcls + C;            // logits [H][N]  (then / followed by)  vbar [N][D]
   float* vbar = MERGED ? region + lg_sz : region;
@@ -71,7 +80,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   float* part = hstat + 2 * H;         // [SS_THREADS]
   float* mean = part + SS_THREADS;     // [D]
   float* misc = mean + D;              // [16]
-  int* wcount = reinterpret_cast<int*>(misc + 16);  // [8]
+  int* wcount = reinterpret_cast<int*>(misc + 16);  // [SS_THREADS / 64]
 
   SS_STAMP(0);
   if (COMPUTE) {
@@ -191,13 +200,14 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     if (MERGED && pow2) {
       // ONE pass over the K and V thirds: per iteration a thread has U K chunks and the H head rows of one V
       // item in flight (every result is the same fixed-order sum as in the two-pass form: bit-identical scores)
+      constexpr int UM = RAJNI_SS_KUM, VU = RAJNI_SS_VUM;
       int n = tid / CP, c = tid - n * CP;
       int nv = grp < ngrp ? grp : N;
       while (n < N || nv < N) {
-        float kf[U][8];
-        int nn[U], cc[U];
+        float kf[UM][8];
+        int nn[UM], cc[UM];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UM; ++u) {
           nn[u] = n; cc[u] = c;
           if (n < N) load8<T>(base + (long)n * 3 * C + C + c * 8, kf[u]);
           n += dn; c += dc;
@@ -206,26 +216,26 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const bool vdo = nv < N;
         const T* vp = base + (long)(vdo ? nv : 0) * 3 * C + 2 * C + sub * 8;
-        float vf[12][8];
+        float vf[VU][8];
 #pragma unroll
-        for (int u = 0; u < 12; ++u)
+        for (int u = 0; u < VU; ++u)
           if (vdo && u < H) load8<T>(vp + u * D, vf[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < UM; ++u)
           if (nn[u] < N) k_item(kf[u], nn[u], cc[u]);
         if (vdo) {
 #pragma unroll
-          for (int u = 0; u < 12; ++u)
+          for (int u = 0; u < VU; ++u)
             if (u < H) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
             }
-          for (int h0 = 12; h0 < H; h0 += 12) {       // more than 12 heads: further rounds of 12
+          for (int h0 = VU; h0 < H; h0 += VU) {       // further rounds of VU head rows, summed in head order
 #pragma unroll
-            for (int u = 0; u < 12; ++u)
+            for (int u = 0; u < VU; ++u)
               if (h0 + u < H) load8<T>(vp + (h0 + u) * D, vf[u]);
 #pragma unroll
-            for (int u = 0; u < 12; ++u)
+            for (int u = 0; u < VU; ++u)
               if (h0 + u < H) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += vf[u][j];
@@ -337,6 +347,12 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   int running = 0;
   // tpt = 1, 2, 4 or 8 lanes share a token's rank count (each a slice of the j range, summed by shuffles): with
   // 197 tokens one lane per token left 60 % of the workgroup idle through a 196-step loop
+  // ranking keys (NaN = +inf) in LDS once - the A_cls region is dead by now - so that the count loop is a 16-byte
+  // broadcast read and four compares per step (one scalar LDS read + NaN test per element, un-pipelined, made this
+  // phase 9 us of the kernel: 100 dependent LDS round trips per lane)
+  float* keys = acls;
+  for (int n = tid; n < N; n += SS_THREADS) keys[n] = rank_key(sc[n]);
+  __syncthreads();
   const int tpt = (N - 1) * 8 <= SS_THREADS ? 8 : (N - 1) * 4 <= SS_THREADS ? 4 : (N - 1) * 2 <= SS_THREADS ? 2 : 1;
   const int per_iter = SS_THREADS / tpt, sl = tid & (tpt - 1);
   const int slice = (N - 1 + tpt - 1) / tpt;
@@ -347,11 +363,14 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     int rank = 0;
     if (valid) {
       si = sc[i];
-      const float ki = rank_key(si);
+      const float ki = keys[i];
       const int j0 = 1 + sl * slice, j1 = j0 + slice < N ? j0 + slice : N;
-      for (int j = j0; j < j1; ++j) {
-        const float kj = rank_key(sc[j]);
-        rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+      // j beats i when its key is larger, or equal with a lower index (the defined tie rule)
+      auto beats = [&](float kj, int j) { return (j >= j0 && j < j1 && (kj > ki || (kj == ki && j < i))) ? 1 : 0; };
+#pragma unroll 4
+      for (int j = j0 & ~3; j < j1; j += 4) {    // aligned 16-byte reads; entries outside [j0, j1) are masked
+        const float4 k4 = *reinterpret_cast<const float4*>(keys + j);   // may run 3 floats into `sc`: masked
+        rank += beats(k4.x, j) + beats(k4.y, j + 1) + beats(k4.z, j + 2) + beats(k4.w, j + 3);
       }
     }
     if (tpt >= 2) rank += __shfl_xor(rank, 1, 64);
@@ -386,8 +405,8 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
 size_t ss_lds_bytes(int N, int H, int D, bool merged) {
   const size_t C = (size_t)H * D;
   const size_t region = merged ? (size_t)((H * N + 3) & ~3) + (size_t)N * D
-                               : (size_t)((H * N > N * D) ? H * N : N * D);
-  return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_THREADS + D + 16 + 8) * sizeof(float);
+                               : (size_t)((((H * N > N * D) ? H * N : N * D) + 3) & ~3);
+  return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_THREADS + D + 16 + SS_THREADS / 64) * sizeof(float);
 }
 
 int g_ss_force_two_pass = 0;   // test hook (rajni_hip_debug.h): 1 = the two-pass layout even when the merged one fits
