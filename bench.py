@@ -435,8 +435,8 @@ def worker(args):
            "model_mfma_frac": round(value * fl_img / 1e12 / (peak_tflops * world), 4),
            "roofline": roofline}
 
-    if headline_workload and world == 1:
-        out["reference_agreement"] = reference_agreement(dev)
+    if headline_workload and world == 1 and not args.no_torch_baseline:   # (skipped with the other side runs when profiling:
+        out["reference_agreement"] = reference_agreement(dev)             #  its 64-image forwards would skew per-kernel averages)
     if hbm_kernels:
         # algorithmic bytes: score+select reads the K and V thirds of qkv once ((2NC + C) x 2 B per image) and writes
         # indices/scores; attention reads the kept q, k, v rows through keep_idx and writes the output (the

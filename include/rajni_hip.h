@@ -46,7 +46,7 @@ enum {
                               model.py:59 (mlp.fc2, ls2, add)                                       */
 };
 
-#define RAJNI_ABI_VERSION 4 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
+#define RAJNI_ABI_VERSION 5 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
 int rajni_abi_version(void); /* == RAJNI_ABI_VERSION of the header the library was built from */
 const char* rajni_last_error(void);
 /* 0 when a gfx950 device is usable by this process, else an error code (message in last_error) */
@@ -90,6 +90,18 @@ int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, 
  * w,b are fp32 [C]. C % 8 == 0. */
 int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,
                     int rows, int C, float eps, int dtype, int x_f32, rajni_stream_t stream);
+/* The same LayerNorm with its output quantised per row for the fp8 matrix pipe (opt-in "fp8_mfma" format, BASELINE
+ * configs[4]; the reference has no fp8 semantics - these are the build's, SURVEY 7 "hard parts"):
+ *   y_scale[r] = max_c |ln(x)[r,c]| / 448   (1 for an all-zero row),   y_q[r,c] = e4m3_rne_sat(ln(x)[r,c] * (1 / y_scale[r]))
+ * with ln(x) evaluated in fp32; y_q is [rows, C] bytes (OCP e4m3 "fn").  When hid_scale != NULL it also receives a
+ * per-row scale for the block's MLP hidden activations, from a bound rather than their maximum (which no GEMM
+ * epilogue can know): |gelu(ln(x) W1^T + b1)| <= ||ln(x)[r]||_2 * max_n ||W1[n]||_2 + max |b1|, so
+ *   hid_scale[r] = (1.0625 * ||ln(x)[r]||_2 * w1_rownorm_max + b1_absmax) / 448   (1 when that is 0);
+ * e4m3 is a floating-point format, so a bound a few binades above the true maximum costs no precision.
+ * x is fp32 when x_f32 != 0, else bf16.  C % 8 == 0, C <= 2048. */
+int rajni_layernorm_fp8(const void* x, long x_row_stride, const float* w, const float* b, void* y_q,
+                        float* y_scale, float* hid_scale, float w1_rownorm_max, float b1_absmax,
+                        int rows, int C, float eps, int x_f32, rajni_stream_t stream);
 
 /* ---- linear layers with fused epilogues (a3, a9, a13, a15) ----
  * y[M,N] = epi(x[M,K] W[N,K]^T).  W must be allocated with its row count padded up to a multiple
@@ -113,6 +125,13 @@ typedef struct {
    * [N(pad256),K], ldw in bytes and a multiple of 16, and w_scale[n] (fp32 [N]) is the dequantisation
    * scale of row n: y = epi(x (q*s)^T) with bf16 x and fp32 accumulation.  dtype must be RAJNI_BF16. */
   const float* w_scale;
+  /* fp8 activations on the fp8 matrix pipe (v_mfma_f32_16x16x128_f8f6f4; requires w_scale): when x_scale != NULL,
+   * `x` holds e4m3 bytes [M,K] (lda in bytes, % 16 == 0) and x_scale[m] (fp32 [M]) is the dequantisation scale of
+   * row m - what rajni_layernorm_fp8 writes: y = epi((xq*xs) (wq*ws)^T), fp32 accumulation.  K % 256 == 0, K >= 512.
+   * With epilogue RAJNI_EPI_BIAS_GELU, y_scale (fp32 [M], required) selects an e4m3 OUTPUT: y is [M,N] bytes
+   * (ldc in bytes, % 16 == 0) holding e4m3_rne_sat(gelu(.) * (1 / y_scale[m])) - the next linear's x / x_scale. */
+  const float* x_scale;
+  const float* y_scale;
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
 
@@ -147,6 +166,9 @@ typedef struct {
   const int32_t* forced_keep_idx; /* test hook: use this selection instead (selection-conditional parity) */
   /* per-row scales of fp8 e4m3 weights (see rajni_linear_args.w_scale); NULL = that weight is `dtype` */
   const float* qkv_s; const float* proj_s; const float* fc1_s; const float* fc2_s;
+  /* act_fp8 plans only: max_n ||W1deq[n,:]||_2 and max_n |b1[n]| of this block's fc1 (the hidden-activation
+   * bound of rajni_layernorm_fp8) */
+  float fc1_rownorm_max, fc1_bias_absmax;
 } rajni_block;
 
 typedef struct {
@@ -171,6 +193,12 @@ typedef struct {
   int resid_bf16;                              /* 0 (default): the residual stream x is kept in fp32 between
                                                   blocks (2x closer to the fp32 reference than a bf16 stream, see
                                                   DESIGN.md); 1: keep it in bf16 like the reference's bf16 model */
+  int act_fp8;                                 /* 1 (opt-in, needs e4m3 block weights): norm1 / norm2 emit per-row
+                                                  scaled e4m3 activations, QKV / FC1 / FC2 run on the fp8 matrix
+                                                  pipe, FC1's GELU epilogue re-quantises the hidden activations
+                                                  (rajni_layernorm_fp8, rajni_linear_args.x_scale).  Attention, proj,
+                                                  patch embed, head and the residual stream are unchanged.
+                                                  C % 256 == 0 and hidden % 256 == 0.  0 (default): bf16 activations */
 } rajni_vit_plan;
 
 size_t rajni_vit_workspace_bytes(const rajni_vit_plan* plan);
@@ -180,7 +208,7 @@ int rajni_vit_forward(const rajni_vit_plan* plan, const void* images, void* logi
 
 /* ---- measurement hooks (bench.py roofline): HIP-event timing per kernel class on the launch
  * stream.  mask bit i enables class i; classes listed by rajni_profile_class_name(). ---- */
-enum { RAJNI_NUM_KCLASS = 13 };
+enum { RAJNI_NUM_KCLASS = 16 };
 void rajni_profile_enable(unsigned mask);
 const char* rajni_profile_class_name(int kclass);
 /* synchronises the recorded events, ADDS them into the accumulators, returns them: per class the

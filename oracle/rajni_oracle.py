@@ -223,16 +223,56 @@ def patch_embed(images: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     return cols @ w.reshape(C, -1).T + b
 
 
+# ----------------------------------------------------------------------------------------------
+# fp8 activations (the build's own opt-in "fp8_mfma" format; the reference has no fp8 semantics - SURVEY 7
+# "hard parts" - so this restates include/rajni_hip.h's rajni_layernorm_fp8 / rajni_linear_args.x_scale rule)
+# ----------------------------------------------------------------------------------------------
+
+def e4m3_rne(v: np.ndarray) -> np.ndarray:
+    """Round to the nearest OCP e4m3 "fn" value (ties to even), saturating at +-448; returns float64 values."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.minimum(np.abs(v), 448.0)
+    e = np.maximum(np.floor(np.log2(np.maximum(a, 2.0 ** -30))), -6.0)     # subnormals share the spacing of 2^-6
+    q = 2.0 ** (e - 3.0)                                                   # 3 mantissa bits
+    return np.sign(v) * np.minimum(np.round(a / q) * q, 448.0)
+
+
+def quantize_rows_e4m3(x: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    """Rows of x [..., C] as the fp8 kernels see them: e4m3(x * (1/scale)) * scale, with the reciprocal and the
+    product in fp32 like the device (so a host restatement reproduces the stored bytes)."""
+    s32 = np.asarray(scale, dtype=np.float32)[..., None]
+    inv = (np.float32(1.0) / s32).astype(np.float32)
+    return e4m3_rne(np.asarray(x, dtype=np.float32) * inv) * s32.astype(np.float64)
+
+
+def row_scale_e4m3(x: np.ndarray) -> np.ndarray:
+    """max |row| / 448 in fp32 (1 for an all-zero row)."""
+    amax = np.abs(np.asarray(x, dtype=np.float32)).max(axis=-1)
+    return np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+
+
+def hidden_scale_bound(xn: np.ndarray, fc1_w: np.ndarray, fc1_b: np.ndarray) -> np.ndarray:
+    """Per-row scale of the MLP hidden activations from the bound |gelu(xn W1^T + b1)| <= ||xn|| max_n ||W1[n]|| + max |b1|
+    (with the 1.0625 margin of rajni_layernorm_fp8), in fp32."""
+    wn = np.float32(np.sqrt((np.asarray(fc1_w, dtype=np.float64) ** 2).sum(axis=1)).max())
+    bm = np.float32(np.abs(fc1_b).max())
+    nrm = np.sqrt((np.asarray(xn, dtype=np.float32).astype(np.float64) ** 2).sum(axis=-1)).astype(np.float32)
+    bound = np.float32(1.0625) * nrm * wn + bm
+    return np.where(bound > 0, bound / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+
+
 def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, depth: int,
                 num_heads: int, ln_eps: float = 1e-6,
                 forced_keep: Optional[Dict[int, np.ndarray]] = None, dtype=np.float64,
-                return_trace: bool = False):
+                return_trace: bool = False, act_fp8: bool = False):
     """RAJNIViTWrapper.forward restated (model.py:30-69) over a timm-named state dict.
 
     returns logits [B,num_classes], stats {"token_counts": [...]}, and (optionally) a per-block
     trace {block: {"scores","keep_idx","next_scores"}} for the scheduled blocks.
     A pos_embed with N-1 rows (timm `no_embed_class`) is added to the patch tokens only - the
     mathematically identical fix for SURVEY B3.
+    `act_fp8`: the build's opt-in fp8 activations - norm1 / norm2 outputs and the MLP hidden activations pass
+    through per-row e4m3 quantisation (see quantize_rows_e4m3) before qkv / fc1 / fc2.
     """
     schedule = normalise_schedule(schedule)
     P = lambda n: np.asarray(sd[n], dtype=dtype)
@@ -255,6 +295,8 @@ def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, dept
         ls1 = P(p + "ls1.gamma") if (p + "ls1.gamma") in sd else None  # model.py:45-48
         ls2 = P(p + "ls2.gamma") if (p + "ls2.gamma") in sd else None
         xn = layer_norm(x, P(p + "norm1.weight"), P(p + "norm1.bias"), ln_eps)
+        if act_fp8:
+            xn = quantize_rows_e4m3(xn, row_scale_e4m3(xn)).astype(dtype)
         if i in schedule:                                              # model.py:50-59
             cfg = schedule[i]
             out, keep_idx, scores, full = rajni_attention(
@@ -270,7 +312,12 @@ def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, dept
             scores = None
         x = x + (out if ls1 is None else out * ls1)                    # model.py:58
         h = layer_norm(x, P(p + "norm2.weight"), P(p + "norm2.bias"), ln_eps)
+        if act_fp8:
+            hs = hidden_scale_bound(h, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"))
+            h = quantize_rows_e4m3(h, row_scale_e4m3(h)).astype(dtype)
         h = gelu(linear(h, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias")))
+        if act_fp8:
+            h = quantize_rows_e4m3(h, hs).astype(dtype)
         h = linear(h, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"))
         x = x + (h if ls2 is None else h * ls2)                        # model.py:59
     x = layer_norm(x[:, 0], P("norm.weight"), P("norm.bias"), ln_eps)  # model.py:65 (CLS row only:

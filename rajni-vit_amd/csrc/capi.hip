@@ -25,7 +25,8 @@ const char* const kNames[RAJNI_NUM_KCLASS] = {
     "gemm_bf16_tn<bias>", "gemm_bf16_tn<bias,gelu>", "gemm_bf16_tn<bias,ls,resid>",
     "gemm_bf16_tn<patch>", "attn_bf16_d64", "layernorm_kernel", "score_select_kernel<fused>",
     "score_select_kernel<scores>", "score_select_kernel<select>", "gather_rows_kernel",
-    "cls_pos_kernel", "other", "gemm_bf16_tn<bias,ls,resid> K<=N"};
+    "cls_pos_kernel", "other", "gemm_bf16_tn<bias,ls,resid> K<=N",
+    "gemm_f8_tn<bias>", "gemm_f8_tn<bias,gelu,requant>", "gemm_f8_tn<bias,ls,resid>"};
 }  // namespace
 
 unsigned long long* rajni_g_stamps = nullptr;
@@ -142,6 +143,13 @@ int rajni_layernorm(const void* x, long x_row_stride, const float* w, const floa
                     int rows, int C, float eps, int dtype, int x_f32, rajni_stream_t stream) {
   NEED_DTYPE("rajni_layernorm");
   return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, x_f32, dtype, (hipStream_t)stream);
+}
+
+int rajni_layernorm_fp8(const void* x, long x_row_stride, const float* w, const float* b, void* y_q,
+                        float* y_scale, float* hid_scale, float w1_rownorm_max, float b1_absmax,
+                        int rows, int C, float eps, int x_f32, rajni_stream_t stream) {
+  return launch_layernorm_fp8(x, x_row_stride, w, b, y_q, y_scale, hid_scale, w1_rownorm_max, b1_absmax, rows, C, eps,
+                              x_f32, (hipStream_t)stream);
 }
 
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream) {

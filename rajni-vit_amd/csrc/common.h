@@ -89,7 +89,8 @@ enum KClass {
   KC_GEMM_BIAS = 0, KC_GEMM_GELU = 1, KC_GEMM_RESID = 2, KC_GEMM_PATCH = 3, KC_ATTENTION = 4,
   KC_LAYERNORM = 5, KC_SCORE_SELECT = 6, KC_IMPORTANCE = 7, KC_SELECT = 8, KC_GATHER = 9,
   KC_CLS_POS = 10, KC_OTHER = 11,
-  KC_GEMM_RESID_SQ = 12   // residual GEMM with K <= N (the attention projection): bound by its fp32-stream epilogue
+  KC_GEMM_RESID_SQ = 12,  // residual GEMM with K <= N (the attention projection): bound by its fp32-stream epilogue
+  KC_GEMM8_BIAS = 13, KC_GEMM8_GELU = 14, KC_GEMM8_RESID = 15   // fp8 x fp8 GEMMs (act_fp8 plans)
 };
 // event bracket around one launch when the class is enabled
 struct ProfScope {
@@ -126,6 +127,8 @@ int launch_patch_embed(const void* images, const void* w, const float* bias, con
 size_t patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype);   // 0: im2col fused into the GEMM loads
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
                      int C, float eps, int x_f32, int dtype, hipStream_t s);
+int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b, void* yq, float* yscale,
+                         float* hscale, float wnorm, float bmax, int rows, int C, float eps, int x_f32, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, int dtype, hipStream_t s);
 int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,

@@ -2,6 +2,9 @@
 // that enqueues every kernel on the caller's stream.  Token counts are data independent,
 // so all shapes are known up front: no allocation, no host sync, no device->host traffic inside.
 //
+// With plan.act_fp8 (opt-in): LN1 / LN2 emit per-row-scaled e4m3 rows, QKV / FC1 / FC2 run on the fp8 matrix pipe
+// (gemm_f8.h) and FC1's GELU epilogue re-quantises the hidden activations; attention, proj, the residual stream,
+// patch embed and head are unchanged.
 // Per block:  LN1 -> QKV GEMM (all N tokens) -> [score+select] -> attention on kept tokens (gather
 // fused into its loads) -> proj GEMM whose epilogue gathers the residual row, applies LayerScale and
 // adds -> LN2 -> FC1 GEMM + GELU -> FC2 GEMM + LayerScale + residual (in place).
@@ -14,6 +17,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
   char *xa, *xb, *xn, *qkv, *att, *hid, *clsn, *scf, *cols;
+  float *xs, *hs;          // act_fp8 plans: per-row scales of the e4m3 LayerNorm output / MLP hidden activations
   size_t total, cols_bytes;
 };
 
@@ -29,9 +33,11 @@ Workspace carve(const rajni_vit_plan& p) {
   const size_t oscf = take(rows * es);
   w.cols_bytes = patch_embed_workspace_bytes(p.B, p.in_chans, p.img_size, p.patch_size, p.dtype);   // 0 when fused
   const size_t ocols = take(w.cols_bytes);
+  const size_t oxs = take(p.act_fp8 ? rows * sizeof(float) : 0), ohs = take(p.act_fp8 ? rows * sizeof(float) : 0);
   char* base = (char*)p.workspace;
   w.xa = base + oxa; w.xb = base + oxb; w.xn = base + oxn; w.qkv = base + oqkv; w.att = base + oatt;
   w.hid = base + ohid; w.clsn = base + ocls; w.scf = base + oscf; w.cols = base + ocols;
+  w.xs = reinterpret_cast<float*>(base + oxs); w.hs = reinterpret_cast<float*>(base + ohs);
   w.total = off;
   return w;
 }
@@ -54,6 +60,14 @@ int check_plan(const rajni_vit_plan& p) {
                 "rajni_vit_forward: C and hidden must be multiples of 64");
   RAJNI_REQUIRE(p.patch_w && p.cls_token && p.pos_embed && p.norm_w && p.norm_b && p.head_w,
                 RAJNI_ERR_INVALID, "rajni_vit_forward: null weight pointer");
+  if (p.act_fp8) {
+    RAJNI_REQUIRE(p.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_vit_forward: act_fp8 needs a bf16 model");
+    RAJNI_REQUIRE(p.C % 256 == 0 && p.hidden % 256 == 0 && p.C >= 512, RAJNI_ERR_UNSUPPORTED,
+                  "rajni_vit_forward: act_fp8 needs C %% 256 == 0, C >= 512 and hidden %% 256 == 0 (C=%d hidden=%d)", p.C, p.hidden);
+    for (int i = 0; i < p.depth; ++i)
+      RAJNI_REQUIRE(p.blocks[i].qkv_s && p.blocks[i].fc1_s && p.blocks[i].fc2_s, RAJNI_ERR_INVALID,
+                    "rajni_vit_forward: act_fp8 needs e4m3 qkv / fc1 / fc2 weights with scales (block %d)", i);
+  }
   return RAJNI_OK;
 }
 
@@ -95,11 +109,13 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (p.token_counts) p.token_counts[i] = N;  // model.py:43
     const int M = B * N;
     // ---- norm1 + qkv on ALL N tokens (model.py:51, attention.py:21-22)
-    rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, dt, s);
+    if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm1_w, blk.norm1_b, w.xn, w.xs, nullptr, 0.f, 0.f, M, C, p.ln_eps, sf32, s);
+    else rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
     rajni_linear_args g{};
     g.dtype = dt;
     g.x = w.xn; g.lda = C; g.w = blk.qkv_w; g.ldw = C; g.bias = blk.qkv_b; g.w_scale = blk.qkv_s;
+    if (p.act_fp8) g.x_scale = w.xs;
     g.y = w.qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epilogue = RAJNI_EPI_BIAS;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
@@ -118,17 +134,21 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
       if (rc != RAJNI_OK) return rc;
       { char* t = cur; cur = oth; oth = t; }
       N = 1;                                          // the stream is now [B, 1, C]
-      rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, B, C, p.ln_eps, sf32, dt, s);
+      if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm2_w, blk.norm2_b, w.xn, w.xs, w.hs, blk.fc1_rownorm_max,
+                                               blk.fc1_bias_absmax, B, C, p.ln_eps, sf32, s);
+      else rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, B, C, p.ln_eps, sf32, dt, s);
       if (rc != RAJNI_OK) return rc;
       g = rajni_linear_args{};
       g.dtype = dt;
       g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b; g.w_scale = blk.fc1_s;
       g.y = w.hid; g.ldc = p.hidden; g.M = B; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
+      if (p.act_fp8) { g.x_scale = w.xs; g.y_scale = w.hs; }
       rc = launch_linear(g, s);
       if (rc != RAJNI_OK) return rc;
       g = rajni_linear_args{};
       g.dtype = dt;
       g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2; g.w_scale = blk.fc2_s;
+      if (p.act_fp8) g.x_scale = w.hs;
       g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = B; g.N = C; g.K = p.hidden;
       g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
       rc = launch_linear(g, s);
@@ -198,17 +218,21 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     N = Np;
 
     // ---- MLP (model.py:59): norm2 -> fc1 + GELU -> fc2 + LayerScale + residual (in place)
-    rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, dt, s);
+    if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm2_w, blk.norm2_b, w.xn, w.xs, w.hs, blk.fc1_rownorm_max,
+                                             blk.fc1_bias_absmax, Mp, C, p.ln_eps, sf32, s);
+    else rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
     g.dtype = dt;
     g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b; g.w_scale = blk.fc1_s;
     g.y = w.hid; g.ldc = p.hidden; g.M = Mp; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
+    if (p.act_fp8) { g.x_scale = w.xs; g.y_scale = w.hs; }   // e4m3 in, e4m3 out (per-row scales)
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
     g.dtype = dt;
     g.x = w.hid; g.lda = p.hidden; g.w = blk.fc2_w; g.ldw = p.hidden; g.bias = blk.fc2_b; g.gamma = blk.ls2; g.w_scale = blk.fc2_s;
+    if (p.act_fp8) g.x_scale = w.hs;
     g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = Mp; g.N = C; g.K = p.hidden;
     g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
     rc = launch_linear(g, s);

@@ -30,13 +30,16 @@
 
 namespace {
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3,
+       EPI_GELU8 = 4 };   // fp8 x fp8 kernel only (gemm_f8.h): bias + GELU, output re-quantised to e4m3 with a per-row scale
 enum { ALOAD_PLAIN = 0, ALOAD_PATCH = 1 };
 
 struct GemmParams {
   const void* X; long lda;      // activations (bf16, or fp32 on the fp32 model path)
   const void* W; long ldw;      // weights, same element type (or fp8 e4m3 bytes, see wscale)
   const float* wscale;          // W8 kernels: W is fp8 e4m3 [N,K] and wscale[n] its per-row dequantisation scale
+  const float* xscale;          // fp8 x fp8 kernel: X is fp8 e4m3 [M,K] and xscale[m] its per-row dequantisation scale
+  const float* yscale;          // ... EPI_GELU8: output row m is stored as e4m3(gelu(.) / yscale[m])
   const float* bias;
   const float* gamma;
   const void* R; long ldr;      // residual stream rows (bf16 or fp32, see SF32)
@@ -202,24 +205,29 @@ constexpr bool nat_order(int epi, bool sf32) { return sf32 && (epi == EPI_RESID 
 //            and the 4 lanes of a row write one whole 64-byte sector per 16-byte store instruction.
 //            (With 16 consecutive columns per lane every store instruction wrote 4 quarter sectors
 //            per row: the wide tiling's epilogue took 9.5k cycles per 256x256 tile, store-issue bound.)
-enum { MAP_NAT = 1, MAP_SEC = 2 };
-constexpr int col_map(int epi, bool sf32) { return nat_order(epi, sf32) ? MAP_NAT : MAP_SEC; }
+//   MAP_F8   col = 16*g + 4*ni + rg           fp8 outputs: a lane owns 16 consecutive columns = one 16-byte store,
+//            the 4 lanes of a row one whole 64-byte sector
+enum { MAP_NAT = 1, MAP_SEC = 2, MAP_F8 = 3 };
+constexpr int col_map(int epi, bool sf32) { return epi == EPI_GELU8 ? MAP_F8 : nat_order(epi, sf32) ? MAP_NAT : MAP_SEC; }
 
 template <int MAP>
 __device__ __forceinline__ int out_col(int n0w, int g, int j) {
   const int ni = j >> 2, rg = j & 3;
-  return MAP == MAP_NAT ? n0w + 16 * ni + 4 * g + rg : n0w + 32 * (ni >> 1) + 8 * g + 4 * (ni & 1) + rg;
+  return MAP == MAP_NAT ? n0w + 16 * ni + 4 * g + rg
+       : MAP == MAP_F8 ? n0w + 16 * g + 4 * ni + rg : n0w + 32 * (ni >> 1) + 8 * g + 4 * (ni & 1) + rg;
 }
 // W tile row (relative to the wave's first W row) read by fragment row l15 of n-tile ni
 template <int MAP>
 __device__ __forceinline__ int w_frag_row(int l15, int ni) {
-  return MAP == MAP_NAT ? ni * 16 + l15 : 32 * (ni >> 1) + 8 * (l15 >> 2) + 4 * (ni & 1) + (l15 & 3);
+  return MAP == MAP_NAT ? ni * 16 + l15
+       : MAP == MAP_F8 ? 16 * (l15 >> 2) + 4 * ni + (l15 & 3) : 32 * (ni >> 1) + 8 * (l15 >> 2) + 4 * (ni & 1) + (l15 & 3);
 }
 // swizzle key of a W tile row for 128-byte-row tilings: the 16 rows one ds_read_b128 lane group
 // touches must land in 16 distinct 16-byte slots of the 256-byte bank row
 template <int MAP>
 __device__ __forceinline__ int w_key(int row) {
-  return MAP == MAP_NAT ? (row >> 1) & 7 : ((row >> 3) & 3) * 2 + ((row >> 1) & 1);
+  return MAP == MAP_NAT ? (row >> 1) & 7
+       : MAP == MAP_F8 ? ((row >> 4) & 3) * 2 + ((row >> 1) & 1) : ((row >> 3) & 3) * 2 + ((row >> 1) & 1);
 }
 
 // ---- fp8 (e4m3) weights: 64-byte tile rows (BK = 64 one-byte elements) -----------------------------
@@ -883,6 +891,8 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
 }
 }  // namespace small
 
+#include "gemm_f8.h"   // namespace f8: the fp8 x fp8 persistent kernel (v_mfma_f32_16x16x128_f8f6f4)
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `done` is the calling site's
 // per-device flag array (a process may drive several GPUs; one process per GPU is the deployment, but a model on
 // cuda:1 in a process whose first launch was on cuda:0 must not inherit that device's "done")
@@ -1187,6 +1197,34 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   return RAJNI_OK;
 }
 
+// fp8 x fp8 launches (gemm_f8.h): one tiling, 256 x 128 x 128, persistent
+template <int EPI, bool SF32>
+int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
+  const int cus = rajni_num_cus();
+  p.tiles_n = (p.N + f8::BN - 1) / f8::BN;
+  const int tiles_m = (p.M + 255) / 256;
+  p.total_tiles = p.tiles_n * tiles_m;
+  p.nblk = n_block(p.tiles_n, tiles_m, f8::BN, p.K, 1, cus);
+  static bool attr[2][RAJNI_MAX_DEVICES] = {};
+  constexpr double ysz = EPI == EPI_GELU8 ? 1.0 : (SF32 && EPI == EPI_RESID) ? 4.0 : 2.0;
+  constexpr double rsz = EPI == EPI_RESID ? (SF32 ? 4.0 : 2.0) : 0.0;
+  ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
+                 (double)p.M * p.K + (ysz + rsz) * (double)p.M * p.N + (double)p.N * p.K);
+  int rc;
+  const int grid = stream_grid(p.total_tiles, cus);
+  if (EPI == EPI_RESID && tag_sq) {
+    if constexpr (EPI == EPI_RESID) {
+      if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 1>, f8::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
+      hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 1>), dim3(grid), dim3(512), f8::LDS_BYTES, s, p);
+    }
+  } else {
+    if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 0>, f8::LDS_BYTES, attr[0])) != RAJNI_OK) return rc;
+    hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 0>), dim3(grid), dim3(512), f8::LDS_BYTES, s, p);
+  }
+  RAJNI_CHECK_LAUNCH("gemm_f8_tn");
+  return RAJNI_OK;
+}
+
 }  // namespace
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
@@ -1212,6 +1250,32 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
   p.Y = a.y; p.ldc = a.ldc;
   p.M = a.M; p.N = a.N; p.K = a.K;
   p.wscale = a.w_scale;
+  if (a.x_scale != nullptr) {   // fp8 e4m3 activations AND weights on the fp8 matrix pipe
+    RAJNI_REQUIRE(a.w_scale != nullptr && a.dtype == RAJNI_BF16, RAJNI_ERR_INVALID,
+                  "rajni_linear: fp8 activations (x_scale) need fp8 weights (w_scale) and dtype bf16");
+    RAJNI_REQUIRE(a.K % 256 == 0 && a.K >= 512, RAJNI_ERR_UNSUPPORTED,
+                  "rajni_linear: the fp8 x fp8 kernel needs K %% 256 == 0 and K >= 512 (K=%d)", a.K);
+    RAJNI_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0, RAJNI_ERR_INVALID, "rajni_linear: fp8 operands need lda, ldw %% 16 == 0 (bytes)");
+    p.xscale = a.x_scale; p.yscale = a.y_scale;
+    switch (a.epilogue) {
+      case RAJNI_EPI_BIAS:
+        RAJNI_REQUIRE(a.y_scale == nullptr, RAJNI_ERR_UNSUPPORTED, "rajni_linear: an fp8 output (y_scale) exists for the GELU epilogue only");
+        return launch_gemm_f8<EPI_BIAS, false>(p, KC_GEMM8_BIAS, false, s);
+      case RAJNI_EPI_BIAS_GELU:
+        RAJNI_REQUIRE(a.y_scale != nullptr && a.ldc % 16 == 0, RAJNI_ERR_UNSUPPORTED,
+                      "rajni_linear: the fp8 x fp8 GELU epilogue writes e4m3 (y_scale required, ldc %% 16 == 0 bytes)");
+        return launch_gemm_f8<EPI_GELU8, false>(p, KC_GEMM8_GELU, false, s);
+      case RAJNI_EPI_BIAS_RESID:
+        RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0 && a.y_scale == nullptr, RAJNI_ERR_INVALID,
+                      "rajni_linear: RESID epilogue needs resid, ldr %% 8 == 0 and no y_scale");
+        return a.stream_f32 ? launch_gemm_f8<EPI_RESID, true>(p, KC_GEMM8_RESID, a.K <= a.N, s)
+                            : launch_gemm_f8<EPI_RESID, false>(p, KC_GEMM8_RESID, a.K <= a.N, s);
+      default:
+        rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
+        return RAJNI_ERR_INVALID;
+    }
+  }
+  RAJNI_REQUIRE(a.y_scale == nullptr, RAJNI_ERR_INVALID, "rajni_linear: y_scale without x_scale");
   if (a.w_scale != nullptr) {   // fp8 e4m3 weights, bf16 activations
     RAJNI_REQUIRE(a.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_linear: fp8 weights need bf16 activations");
     RAJNI_REQUIRE(a.ldw % 16 == 0, RAJNI_ERR_INVALID, "rajni_linear: fp8 weights need ldw %% 16 == 0");

@@ -56,6 +56,93 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
   }
 }
 
+// LayerNorm whose output row is quantised for the fp8 matrix pipe (see rajni_layernorm_fp8 in the header): the
+// wave holds the whole normalised row in registers, so the row maximum is one more wave reduction.
+//   yscale[r] = max |o| / 448 (1 if 0);  yq = e4m3_rne_sat(o * (1 / yscale[r]))   - the reciprocal is a correctly
+//   rounded fp32 division and the product one fp32 multiply, so a host restatement reproduces the bytes;
+//   hscale[r] (optional) = (1.0625 * ||o||_2 * wnorm + bmax) / 448: per-row scale of the MLP hidden activations
+//   from the Cauchy-Schwarz bound (the margin covers the <= 2^-4 relative change of ||o|| under quantisation).
+template <typename TX>
+__global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict__ x, long xs,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            unsigned char* __restrict__ yq, float* __restrict__ yscale,
+                                                            float* __restrict__ hscale, float wnorm, float bmax,
+                                                            int rows, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nchunk = C >> 3;
+  const TX* xr = x + (long)row * xs;
+  float v[LN_MAX_CHUNKS][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      load8<TX>(xr + c * 8, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  float amax = 0.f, osq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float wv[8], bv[8];
+      load8<float>(w + c * 8, wv);
+      load8<float>(b + c * 8, bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float o = fmaf((v[i][j] - mean) * rstd, wv[j], bv[j]);
+        v[i][j] = o;
+        amax = fmaxf(amax, fabsf(o));
+        osq = fmaf(o, o, osq);
+      }
+    }
+  }
+  amax = wave_max(amax);
+  osq = wave_sum(osq);
+  const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+  const float inv = 1.0f / scale;
+  unsigned char* yr = yq + (long)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = __builtin_amdgcn_fmed3f(v[i][j] * inv, -448.f, 448.f);
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+      *reinterpret_cast<uint2*>(yr + c * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+  }
+  if (lane == 0) {
+    yscale[row] = scale;
+    if (hscale != nullptr) {
+      const float bound = fmaf(1.0625f * sqrtf(osq), wnorm, bmax);
+      hscale[row] = bound > 0.f ? bound / 448.0f : 1.0f;
+    }
+  }
+}
+
 // dst[b, j, :] = src[b, idx[b, j], :]   rows of `row_chunks` 16-byte chunks; one wave per row
 __global__ void __launch_bounds__(256) gather_rows_kernel(const uint4* __restrict__ src,
                                                          const int* __restrict__ idx,
@@ -89,6 +176,24 @@ int launch_layernorm(const void* x, long xs, const float* w, const float* b, voi
   else
     hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (bf16_t*)y, rows, C, eps);
   RAJNI_CHECK_LAUNCH("layernorm_kernel");
+  return RAJNI_OK;
+}
+
+int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b, void* yq, float* yscale,
+                         float* hscale, float wnorm, float bmax, int rows, int C, float eps, int x_f32, hipStream_t s) {
+  RAJNI_REQUIRE(x && w && b && yq && yscale, RAJNI_ERR_INVALID, "rajni_layernorm_fp8: null pointer");
+  RAJNI_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS && xs % 8 == 0,
+                RAJNI_ERR_UNSUPPORTED, "rajni_layernorm_fp8: need C %% 8 == 0, C <= 2048, stride %% 8 == 0 (C=%d)", C);
+  RAJNI_REQUIRE(wnorm >= 0.f && bmax >= 0.f, RAJNI_ERR_INVALID, "rajni_layernorm_fp8: the hidden bound's constants must be >= 0");
+  ProfScope prof(KC_LAYERNORM, s, 10.0 * rows * C, (x_f32 ? 5.0 : 3.0) * rows * C);
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (x_f32)
+    hipLaunchKernelGGL((layernorm_fp8_kernel<float>), grid, block, 0, s, (const float*)x, xs, w, b, (unsigned char*)yq,
+                       yscale, hscale, wnorm, bmax, rows, C, eps);
+  else
+    hipLaunchKernelGGL((layernorm_fp8_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (unsigned char*)yq,
+                       yscale, hscale, wnorm, bmax, rows, C, eps);
+  RAJNI_CHECK_LAUNCH("layernorm_fp8_kernel");
   return RAJNI_OK;
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RAJNI_HIP_LIB") or os.path.join(_HERE, "lib", "libraj
 
 RAJNI_F32, RAJNI_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2
-NUM_KCLASS = 13
+NUM_KCLASS = 16
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -30,7 +30,8 @@ class LinearArgs(C.Structure):
                 ("bias", c_void_p), ("gamma", c_void_p), ("resid", c_void_p), ("ldr", c_long),
                 ("r_idx", c_void_p), ("r_np", c_int), ("r_nsrc", c_int),
                 ("y", c_void_p), ("ldc", c_long), ("M", c_int), ("N", c_int), ("K", c_int),
-                ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int), ("w_scale", c_void_p)]
+                ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int), ("w_scale", c_void_p),
+                ("x_scale", c_void_p), ("y_scale", c_void_p)]
 
 
 class Block(C.Structure):
@@ -43,7 +44,8 @@ class Block(C.Structure):
                 ("keep", c_int), ("update", c_int),
                 ("keep_idx", c_void_p), ("scores", c_void_p), ("next_scores", c_void_p),
                 ("forced_keep_idx", c_void_p),
-                ("qkv_s", c_void_p), ("proj_s", c_void_p), ("fc1_s", c_void_p), ("fc2_s", c_void_p)]
+                ("qkv_s", c_void_p), ("proj_s", c_void_p), ("fc1_s", c_void_p), ("fc2_s", c_void_p),
+                ("fc1_rownorm_max", c_float), ("fc1_bias_absmax", c_float)]
 
 
 class VitPlan(C.Structure):
@@ -56,7 +58,7 @@ class VitPlan(C.Structure):
                 ("norm_w", c_void_p), ("norm_b", c_void_p), ("head_w", c_void_p), ("head_b", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int), ("cls_only_last_block", c_int),
-                ("resid_bf16", c_int)]
+                ("resid_bf16", c_int), ("act_fp8", c_int)]
 
 
 _SIGS = {
@@ -72,6 +74,8 @@ _SIGS = {
                                 c_int, c_void_p]),
     "rajni_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                 c_int, c_int, c_void_p]),
+    "rajni_layernorm_fp8": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                    c_int, c_int, c_float, c_int, c_void_p]),
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "rajni_debug_force_gemm_tiling": (None, [c_int]),
     "rajni_debug_set_gemm_nblock_bytes": (None, [c_int]),
@@ -91,7 +95,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
-ABI_VERSION = 4     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
+ABI_VERSION = 5     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
 _lib: Optional[C.CDLL] = None
 
 

@@ -174,29 +174,60 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, row
     return out
 
 
+def layernorm_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
+                  hidden_bound: Optional[Tuple[float, float]] = None):
+    """LayerNorm over the last axis with the output row quantised for the fp8 matrix pipe (rajni_layernorm_fp8):
+    returns (q uint8 [..., C] of e4m3 bytes, scale fp32 [rows]) and, with `hidden_bound = (max row norm of the
+    dequantised fc1 weight, max |fc1 bias|)`, also the per-row scale of the MLP hidden activations."""
+    nat.require_device(x, "x")
+    x = x.contiguous()
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError("layernorm_fp8: x must be fp32 (the residual stream) or bf16")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    hs = torch.empty(rows, dtype=torch.float32, device=x.device) if hidden_bound is not None else None
+    wn, bm = (float(hidden_bound[0]), float(hidden_bound[1])) if hidden_bound is not None else (0.0, 0.0)
+    with nat.device_guard(x.device):
+        nat.check(nat.lib().rajni_layernorm_fp8(x.data_ptr(), Cc, w.data_ptr(), b.data_ptr(), q.data_ptr(), scale.data_ptr(),
+                                                nat.ptr(hs), wn, bm, rows, Cc, float(eps), int(x.dtype == torch.float32),
+                                                nat.stream_ptr(x.device)), "rajni_layernorm_fp8")
+    return (q, scale) if hs is None else (q, scale, hs)
+
+
 def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None,
            epilogue: int = nat.EPI_BIAS, gamma: Optional[torch.Tensor] = None,
            resid: Optional[torch.Tensor] = None, r_idx: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None,
+           x_scale: Optional[torch.Tensor] = None, y_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x @ W^T): x [..., K]; w_packed from pack_weight(); bias/gamma fp32 [n_out].
     With `w_scale` (fp32 [n_out]) w_packed is the uint8 e4m3 tensor of pack_weight_fp8() and x is bf16.
     resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID; an fp32
-    resid selects the fp32 residual stream (the output is then fp32 too)."""
+    resid selects the fp32 residual stream (the output is then fp32 too).
+    With `x_scale` (fp32 [M]) x is the uint8 e4m3 tensor of layernorm_fp8() and the product runs on the fp8 matrix
+    pipe (w_scale required); with EPI_BIAS_GELU `y_scale` (fp32 [M]) is required and the result is uint8 e4m3."""
     nat.require_device(x, "x")
     x = x.contiguous()
     K = x.shape[-1]
     M = x.numel() // K
-    ld = (n_out + 7) // 8 * 8
-    stream_f32 = int(resid is not None and resid.dtype == torch.float32 and x.dtype != torch.float32)
+    f8 = x_scale is not None
+    if f8 and (x.dtype != torch.uint8 or w_scale is None):
+        raise ValueError("x_scale needs the uint8 e4m3 activations of layernorm_fp8() and fp8 weights (w_scale)")
+    act_dtype = torch.bfloat16 if f8 else x.dtype
+    out8 = f8 and epilogue == nat.EPI_BIAS_GELU
+    ld = (n_out + 15) // 16 * 16 if out8 else (n_out + 7) // 8 * 8
+    stream_f32 = int(resid is not None and resid.dtype == torch.float32 and act_dtype != torch.float32)
     if out is None:
-        out = torch.empty((M, ld), dtype=torch.float32 if stream_f32 else x.dtype, device=x.device)
+        out = torch.empty((M, ld), dtype=torch.uint8 if out8 else (torch.float32 if stream_f32 else act_dtype), device=x.device)
     a = nat.LinearArgs()
     a.x, a.lda, a.w, a.ldw = x.data_ptr(), K, w_packed.data_ptr(), w_packed.shape[1]
     a.bias, a.gamma, a.w_scale = nat.ptr(bias), nat.ptr(gamma), nat.ptr(w_scale)
     if w_scale is not None and w_packed.dtype != torch.uint8:
         raise ValueError("w_scale given but w_packed is not the uint8 tensor of pack_weight_fp8()")
     a.y, a.ldc = out.data_ptr(), out.shape[-1] if out.dim() == 2 else out.stride(-2)
-    a.M, a.N, a.K, a.epilogue, a.dtype, a.stream_f32 = M, n_out, K, epilogue, _dt(x), stream_f32
+    a.M, a.N, a.K, a.epilogue, a.dtype, a.stream_f32 = M, n_out, K, epilogue, nat.dtype_code(act_dtype), stream_f32
+    a.x_scale, a.y_scale = nat.ptr(x_scale), nat.ptr(y_scale)
     if resid is not None:
         resid = resid.contiguous()
         a.resid, a.ldr = resid.data_ptr(), resid.shape[-1]

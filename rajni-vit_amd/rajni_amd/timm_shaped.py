@@ -78,6 +78,8 @@ CONFIGS: Dict[str, ViTConfig] = {
     # the same with DeiT-3's LayerScale and no_embed_class pos-embed (N-1 rows): loader / B3 tests (not a timm name)
     "deit3_micro_patch16_64": ViTConfig(img_size=64, embed_dim=128, depth=4, num_heads=2, num_classes=10,
                                         layer_scale=1e-6, no_embed_class=True),
+    # embed dim 512 / MLP width 2048 (multiples of 256, K >= 512: what the fp8 x fp8 kernel needs) at micro cost (not a timm name)
+    "vit_micro512_patch16_64": ViTConfig(img_size=64, embed_dim=512, depth=4, num_heads=8, num_classes=10),
     # patch 14 (ViT-L/14, ViT-H/14, DINOv2): 3*14*14 = 588 input features, not whole 64-wide K steps
     "vit_micro_patch14_56": ViTConfig(img_size=56, patch_size=14, embed_dim=128, depth=4, num_heads=2,
                                       num_classes=10),

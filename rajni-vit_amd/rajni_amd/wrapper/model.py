@@ -113,11 +113,18 @@ class RAJNIViTWrapper(nn.Module):
         return self
 
     def set_weight_format(self, fmt: str):
-        """"model" (default) or "fp8": keep qkv/proj/fc1/fc2 weights as fp8 e4m3 with one fp32 scale per
-        output row (BASELINE config 5).  Activations, accumulation, patch-embed and
-        head stay as they are; results equal the same model run with the DEQUANTISED weights."""
-        if fmt not in ("model", "fp8"):
-            raise ValueError('weight format must be "model" or "fp8"')
+        """"model" (default), "fp8" or "fp8_mfma".
+        "fp8": keep qkv/proj/fc1/fc2 weights as fp8 e4m3 with one fp32 scale per output row (BASELINE config 5,
+        SURVEY 8(f)-4).  Activations, accumulation, patch-embed and head stay as they are; results equal the same
+        model run with the DEQUANTISED weights (the bf16 matrix pipe does the arithmetic).
+        "fp8_mfma": the same weights, AND the inputs of qkv / fc1 / fc2 as per-row-scaled e4m3 (norm1 / norm2 emit
+        them, fc1's GELU epilogue re-quantises the hidden activations), so that those three products run on the
+        CDNA4 fp8 matrix pipe (v_mfma_f32_16x16x128_f8f6f4, fp32 accumulation).  Results equal the model run with
+        the dequantised weights and the same activation quantisation (tests/test_gpu_fp8_mfma.py holds the rule);
+        the reference has no fp8 semantics, so this is an opt-in numerics contract of the build's own.  Needs
+        embed dim and MLP width that are multiples of 256."""
+        if fmt not in ("model", "fp8", "fp8_mfma"):
+            raise ValueError('weight format must be "model", "fp8" or "fp8_mfma"')
         if fmt != self._weight_format:
             self._weight_format = fmt
             self._weights = self._weights_key = None
@@ -127,8 +134,8 @@ class RAJNIViTWrapper(nn.Module):
     def dequantized_state_dict(self):
         """fp32 copies of the block Linear weights as the fp8 kernels see them (q * scale), keyed like the
         base model's state_dict.  Test surface: feed these to the oracle for the fp8 parity check."""
-        if self._weights is None or self._weight_format != "fp8":
-            raise RuntimeError("run a forward with set_weight_format('fp8') first")
+        if self._weights is None or self._weight_format not in ("fp8", "fp8_mfma"):
+            raise RuntimeError("run a forward with set_weight_format('fp8') or ('fp8_mfma') first")
         out = {}
         hid = self._weights["desc"]["hidden"]
         for i, bw in enumerate(self._weights["blocks"]):
@@ -242,7 +249,7 @@ class RAJNIViTWrapper(nn.Module):
             return self._weights
         desc = self._describe()
         m = self.m
-        fp8 = self._weight_format == "fp8"
+        fp8 = self._weight_format in ("fp8", "fp8_mfma")
         if fp8 and dtype != torch.bfloat16:
             raise NotImplementedError("fp8 weights need a bf16 model (activations stay bf16)")
         pw = lambda w: ops.pack_weight(w, dtype, device)
@@ -293,6 +300,12 @@ class RAJNIViTWrapper(nn.Module):
                 ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
                 fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=fc1_b,
                 fc2_w=fc2_w, fc2_s=fc2_s, fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
+            if self._weight_format == "fp8_mfma":
+                # constants of the hidden-activation bound (rajni_layernorm_fp8): largest row norm of the DEQUANTISED
+                # fc1 weight and largest |bias| as the kernels hold it
+                wd = ops.dequantize_fp8(fc1_w, fc1_s)
+                blocks[-1]["fc1_rownorm_max"] = float(wd.norm(dim=1).max())
+                blocks[-1]["fc1_bias_absmax"] = float(fc1_b.abs().max())
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
         self._drop_plans()
@@ -327,6 +340,8 @@ class RAJNIViTWrapper(nn.Module):
             for name in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "norm2_w", "norm2_b",
                          "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s"):
                 setattr(cb, name, nat.ptr(bw[name]))
+            if self._weight_format == "fp8_mfma":
+                cb.fc1_rownorm_max, cb.fc1_bias_absmax = bw["fc1_rownorm_max"], bw["fc1_bias_absmax"]
             if i in self.pruning_schedule:
                 cfg = self.pruning_schedule[i]
                 N = counts[i]
@@ -365,6 +380,7 @@ class RAJNIViTWrapper(nn.Module):
         plan.logits_ld = (d["num_classes"] + 7) // 8 * 8
         plan.resid_bf16 = int(self._resid_bf16)
         plan.cls_only_last_block = int(self._cls_only_last)
+        plan.act_fp8 = int(self._weight_format == "fp8_mfma")
         nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes

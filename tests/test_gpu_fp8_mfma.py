@@ -1,0 +1,204 @@
+"""The opt-in fp8 path of BASELINE.json configs[4] ("deit3_base_patch16_224 fp8 weights (CDNA4 fp8 MFMA)"):
+`set_weight_format("fp8_mfma")` = e4m3 block weights AND per-row-scaled e4m3 inputs of qkv / fc1 / fc2 on
+v_mfma_f32_16x16x128_f8f6f4.  GPU box only (`-m gpu`).
+
+The reference has no fp8 semantics (SURVEY 7 "hard parts"), so parity is defined the way tests/test_gpu_fp8.py
+defines it for weights: the ORACLE run on the DEQUANTISED operands - here the dequantised weights and the same
+activation-quantisation rule (oracle.quantize_rows_e4m3 / row_scale_e4m3 / hidden_scale_bound, which restate
+include/rajni_hip.h's rajni_layernorm_fp8) - and the cost of quantisation against the reference fixture is reported."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import rajni_amd
+from oracle import rajni_oracle as orc
+from rajni_amd import ops, timm_shaped as ts, _native as nat
+from rajni_amd.timm_shaped import bf16_round_np
+from helpers import load_case, case_images, pruned_blocks
+
+DEV = "cuda"
+
+
+def e4m3_bytes_to_f64(q: torch.Tensor) -> np.ndarray:
+    return q.cpu().view(torch.float8_e4m3fn).to(torch.float32).numpy().astype(np.float64)
+
+
+def random_e4m3(rng, shape):
+    """uniform random e4m3 codes without the two NaN patterns (0x7F, 0xFF)"""
+    b = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    b[(b & 0x7F) == 0x7F] = 0x38
+    return b
+
+
+@pytest.mark.parametrize("rows,Cc,x_f32", [(300, 768, True), (64, 512, False), (1000, 1024, True), (5, 256, True)])
+def test_layernorm_fp8_rule(rows, Cc, x_f32):
+    rng = np.random.default_rng(rows + Cc)
+    x = rng.standard_normal((rows, Cc), dtype=np.float32) * rng.uniform(0.05, 30.0, size=(rows, 1)).astype(np.float32)
+    x += rng.standard_normal((rows, 1), dtype=np.float32) * 3
+    x[rows // 2] = 0.0                                   # an all-zero row (after the affine map: the bias row)
+    if not x_f32:
+        x = bf16_round_np(x)
+    w = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    b = (0.05 * rng.standard_normal(Cc)).astype(np.float32)
+    xt = torch.from_numpy(x).to(DEV) if x_f32 else torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    wn, bm = 0.61, 0.07
+    q, s, hs = ops.layernorm_fp8(xt, torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), 1e-6, hidden_bound=(wn, bm))
+    o = orc.layer_norm(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 1e-6)
+    s_ref = np.abs(o).max(axis=1) / 448.0
+    s_dev = s.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(s_dev, s_ref, rtol=2e-5)
+    deq = e4m3_bytes_to_f64(q) * s_dev[:, None]
+    # e4m3: 3 mantissa bits -> half an ulp is 2^-4 relative in the normal range, 2^-10 * scale absolute below it
+    bound = np.maximum(np.abs(o) * 2.0 ** -4, s_dev[:, None] * 2.0 ** -10) * 1.001 + 1e-6 * np.abs(o).max()
+    assert (np.abs(deq - o) <= bound).all()
+    # and byte for byte the stated rule on the device's own fp32 scale (the rare differences are elements whose fp32
+    # LayerNorm value sits within an fp32 ulp of a rounding boundary)
+    want = orc.quantize_rows_e4m3(o, s_dev.astype(np.float32))
+    assert np.mean(want != deq) < 2e-3
+    hs_ref = (1.0625 * np.sqrt((o ** 2).sum(axis=1)) * wn + bm) / 448.0
+    np.testing.assert_allclose(hs.cpu().numpy(), hs_ref, rtol=2e-5)
+
+
+def _f8_operands(rng, M, N, K):
+    xq, wq = random_e4m3(rng, (M, K)), random_e4m3(rng, (N, K))
+    # keep products tame: scales so that dequantised entries are O(1)
+    xs = (rng.uniform(0.5, 2.0, size=M) / 64.0).astype(np.float32)
+    ws = (rng.uniform(0.5, 2.0, size=N) / 64.0).astype(np.float32)
+    npad = (N + 255) // 256 * 256
+    wp = np.zeros((npad, K), np.uint8)
+    wp[:N] = wq
+    xd = e4m3_bytes_to_f64(torch.from_numpy(xq)) * xs[:, None]
+    wd = e4m3_bytes_to_f64(torch.from_numpy(wq)) * ws[:, None]
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    return dev(xq), dev(xs), dev(wp), dev(ws), xd, wd
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 512), (700, 768, 768), (50, 2304, 768), (1030, 200, 1024), (513, 3072, 768)])
+def test_linear_f8_bias(M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    xq, xs, wp, ws, xd, wd = _f8_operands(rng, M, N, K)
+    b = rng.standard_normal(N).astype(np.float32)
+    y = ops.linear(xq, wp, N, torch.from_numpy(b).to(DEV), nat.EPI_BIAS, w_scale=ws, x_scale=xs)
+    assert y.dtype == torch.bfloat16
+    want = xd @ wd.T + b
+    got = y.float().cpu().numpy()[:, :N]
+    assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (700, 3072, 768), (60, 1000, 1024), (1300, 520, 768)])
+def test_linear_f8_gelu_requant(M, N, K):
+    """fc1 on the fp8 pipe: bias + exact-erf GELU, output re-quantised to e4m3 with the given per-row scale."""
+    rng = np.random.default_rng(M * 3 + N + K)
+    xq, xs, wp, ws, xd, wd = _f8_operands(rng, M, N, K)
+    b = rng.standard_normal(N).astype(np.float32)
+    pre = xd @ wd.T + b
+    h = orc.gelu(pre)
+    ys = (np.abs(pre).max(axis=1) * rng.uniform(1.0, 8.0, size=M) / 448.0).astype(np.float32)   # a bound, not the max
+    y = ops.linear(xq, wp, N, torch.from_numpy(b).to(DEV), nat.EPI_BIAS_GELU, w_scale=ws, x_scale=xs,
+                   y_scale=torch.from_numpy(ys).to(DEV))
+    assert y.dtype == torch.uint8
+    deq = e4m3_bytes_to_f64(y)[:, :N] * ys[:, None].astype(np.float64)
+    bound = np.maximum(np.abs(h) * 2.0 ** -4, ys[:, None] * 2.0 ** -10) * 1.01 + 2e-4 * np.abs(h).max()
+    assert (np.abs(deq - h) <= bound).all()
+    want = orc.quantize_rows_e4m3(h, ys)
+    assert np.mean(want != deq) < 5e-3          # fp32 accumulation order + the 4e-5 GELU polynomial near boundaries
+
+
+@pytest.mark.parametrize("M,N,K,gather", [(512, 768, 3072, False), (700, 768, 1024, True), (90, 256, 512, False),
+                                          (1280, 520, 768, False)])
+def test_linear_f8_resid_fp32_stream(M, N, K, gather):
+    """fc2 on the fp8 pipe: y = gamma * (xd wd^T + b) + resid on the fp32 residual stream (optionally gathered rows)."""
+    rng = np.random.default_rng(M + 7 * N + K)
+    xq, xs, wp, ws, xd, wd = _f8_operands(rng, M, N, K)
+    b = rng.standard_normal(N).astype(np.float32)
+    gam = rng.uniform(0.2, 1.5, size=N).astype(np.float32)
+    if gather:
+        Bb, Np, Nsrc = 7, M // 7, M // 7 + 20
+        idx = np.stack([np.sort(rng.choice(Nsrc, Np, replace=False)) for _ in range(Bb)]).astype(np.int32)
+        resid = rng.standard_normal((Bb, Nsrc, N)).astype(np.float32)
+        r_rows = np.take_along_axis(resid, idx[:, :, None].astype(np.int64), axis=1).reshape(M, N)
+        y = ops.linear(xq.reshape(Bb, Np, K), wp, N, torch.from_numpy(b).to(DEV), nat.EPI_BIAS_RESID,
+                       gamma=torch.from_numpy(gam).to(DEV), resid=torch.from_numpy(resid).to(DEV),
+                       r_idx=torch.from_numpy(idx).to(DEV), w_scale=ws, x_scale=xs)
+    else:
+        resid = rng.standard_normal((1, M, N)).astype(np.float32)
+        r_rows = resid[0]
+        y = ops.linear(xq, wp, N, torch.from_numpy(b).to(DEV), nat.EPI_BIAS_RESID, gamma=torch.from_numpy(gam).to(DEV),
+                       resid=torch.from_numpy(resid).to(DEV), w_scale=ws, x_scale=xs)
+    assert y.dtype == torch.float32
+    want = gam * (xd @ wd.T + b) + r_rows
+    got = y.cpu().numpy().reshape(M, -1)[:, :N]
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def _build_f8(cfg_name, sched, seed, std=0.06):
+    cfg = ts.CONFIGS[cfg_name]
+    model = ts.create_model(cfg, seed=seed, std=std, bias_std=0.02, round_bf16=True)
+    w = rajni_amd.RAJNIViTWrapper(model, sched).to(DEV).to(torch.bfloat16).eval()
+    return cfg, model, w
+
+
+def _oracle_fp8(cfg, model, wrapped, imgs, sched, forced):
+    sd = ts.state_dict_numpy(model)
+    sd.update({k: v.cpu().numpy() for k, v in wrapped.dequantized_state_dict().items()})
+    return orc.vit_forward(sd, imgs, sched, depth=cfg.depth, num_heads=cfg.num_heads, ln_eps=cfg.ln_eps,
+                           forced_keep=forced, act_fp8=True)
+
+
+@pytest.mark.parametrize("batch", [3, 40])
+def test_forward_fp8_mfma_vs_oracle_micro(batch):
+    """Whole forward, C = 512 micro model: logits vs the oracle with dequantised weights, the device's selections and
+    the same activation-quantisation rule; token counts exact.  batch 3 exercises M < 256 launches (clamped rows)."""
+    sched = {1: {"keep_ratio": 0.75, "update": True}, 2: {"keep_ratio": 0.6, "update": False}}
+    cfg, model, w = _build_f8("vit_micro512_patch16_64", sched, seed=4)
+    w.set_weight_format("fp8_mfma")
+    imgs = bf16_round_np(np.random.default_rng(9).standard_normal((batch, 3, 64, 64), dtype=np.float32))
+    got = w(torch.from_numpy(imgs).to(DEV)).float().cpu().numpy()
+    forced = {i: t["keep_idx"].cpu().numpy() for i, t in w.get_last_trace().items()}
+    want, stats = _oracle_fp8(cfg, model, w, imgs, sched, forced)
+    assert stats == w.get_last_stats()
+    err, scale = np.abs(got - want).max(), np.abs(want).max()
+    print(f"\nfp8_mfma micro512 batch {batch}: max |dlogit| {err:.4g} abs = {err / scale:.4g} of the logit scale {scale:.3g}")
+    assert err <= 1.5e-2 * scale
+    # the opt-in format is a different numerics contract, not a different function: close to the fp8-weights-only run
+    w.set_weight_format("fp8")
+    w.force_keep_idx({i: torch.from_numpy(v).to(DEV) for i, v in forced.items()})
+    ref8 = w(torch.from_numpy(imgs).to(DEV)).float().cpu().numpy()
+    print(f"   activation-quantisation cost vs fp8 weights only: {np.abs(got - ref8).max() / scale:.4g} of the logit scale")
+    assert np.abs(got - ref8).max() <= 0.25 * scale
+
+
+@pytest.mark.parametrize("name", ["base224_fp32", "deit3_fp32"])
+def test_forward_fp8_mfma_fixtures(name):
+    """ViT-B / DeiT-3-B dims (configs[4]'s model) on the reference fixtures: parity vs the oracle on dequantised
+    operands with the reference's selections injected, and the reported cost of the whole quantisation (weights +
+    activations) against the reference's fp32 logits."""
+    meta, data = load_case(name)
+    cfg = ts.CONFIGS[meta["cfg_name"]]
+    model = ts.create_model(cfg, seed=meta["seed"], std=meta["std"], bias_std=meta["bias_std"], round_bf16=True)
+    w = rajni_amd.RAJNIViTWrapper(model, meta["schedule"]).to(DEV).to(torch.bfloat16).eval()
+    w.set_weight_format("fp8_mfma")
+    imgs = case_images(meta, data)
+    forced = {i: data[f"blk{i}.keep_idx"] for i in pruned_blocks(meta)}
+    w.force_keep_idx({i: torch.from_numpy(v).to(DEV) for i, v in forced.items()})
+    got = w(torch.from_numpy(imgs).to(DEV)).float().cpu().numpy()
+    assert w.get_last_stats()["token_counts"] == data["token_counts"].tolist()
+    want, _ = _oracle_fp8(cfg, model, w, imgs, meta["schedule"], forced)
+    scale = np.abs(data["logits"]).max()
+    err = np.abs(got - want).max()
+    cost = np.abs(got - data["logits"]).max()
+    print(f"\nfp8_mfma {name}: vs oracle on dequantised operands {err:.4g} abs = {err / scale:.4g} rel; "
+          f"quantisation cost vs the reference fp32 logits {cost:.4g} abs = {cost / scale:.4g} rel (logit scale {scale:.3g})")
+    assert err <= 1.5e-2 * scale
+    assert cost <= 0.35 * scale
+
+
+def test_fp8_mfma_refuses_unsupported_shapes():
+    """Embed dims that are not multiples of 256 (ViT-Ti: 192) are refused, not mis-computed."""
+    cfg = ts.CONFIGS["vit_micro_patch16_64"]            # C = 128
+    w = rajni_amd.RAJNIViTWrapper(ts.create_model(cfg, seed=1), {}).to(DEV).to(torch.bfloat16).eval()
+    w.set_weight_format("fp8_mfma")
+    with pytest.raises(NotImplementedError, match="act_fp8"):
+        w(torch.randn(2, 3, 64, 64, device=DEV))

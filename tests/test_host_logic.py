@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert set(nat.EXPORTED_SYMBOLS) == declared
-    assert lib.rajni_abi_version() == nat.ABI_VERSION == 4
+    assert lib.rajni_abi_version() == nat.ABI_VERSION == 5
     assert lib.rajni_profile_class_name(0).decode().startswith("gemm")
 
 

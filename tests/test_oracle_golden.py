@@ -165,3 +165,24 @@ def test_torch_oracle_selection_rule_is_the_numpy_oracles():
     for keep in (1, 10, 49):
         np.testing.assert_array_equal(ort.select_tokens(torch.from_numpy(s), keep).numpy(), orc.select_tokens(s, keep))
     assert [ort.keep_count(r, n) for r, n in [(0.88, 197), (0.0, 197), (1.0, 197)]] == [orc.keep_count(r, n) for r, n in [(0.88, 197), (0.0, 197), (1.0, 197)]]
+
+
+def test_e4m3_rounding_matches_torch_float8():
+    """oracle.e4m3_rne (the rounding rule of the build's opt-in fp8 activations) is round-to-nearest-even onto the
+    OCP e4m3 "fn" grid with saturation at 448 - pinned against torch's float8_e4m3fn cast on a million values over
+    six decades, plus ties, subnormals and the saturation edge."""
+    import torch
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.standard_normal(200_000) * s for s in (1e-3, 1e-2, 0.1, 1, 10, 100)]).astype(np.float32)
+    v = np.clip(v, -448, 448)
+    t = torch.from_numpy(v).to(torch.float8_e4m3fn).to(torch.float32).numpy()
+    assert np.array_equal(orc.e4m3_rne(v), t.astype(np.float64))
+    edge = np.array([0, 2 ** -10, 2 ** -9, 1.5 * 2 ** -9, 448, 447, 17, 18, 19, 0.4375, 0.46875, -0.46875], dtype=np.float32)
+    assert np.array_equal(orc.e4m3_rne(edge), torch.from_numpy(edge).to(torch.float8_e4m3fn).to(torch.float32).numpy())
+    assert orc.e4m3_rne(np.array([1e9, -1e9, 464.0])).tolist() == [448.0, -448.0, 448.0]      # saturating
+    # quantize_rows_e4m3: scale = max / 448 maps the row maximum onto the top code
+    x = rng.standard_normal((5, 64)).astype(np.float32)
+    s = orc.row_scale_e4m3(x)
+    d = orc.quantize_rows_e4m3(x, s)
+    assert np.allclose(np.abs(d).max(axis=1), np.abs(x).max(axis=1), rtol=1e-6)
+    assert (np.abs(d - x) <= np.maximum(np.abs(x) * 2.0 ** -4, s[:, None] * 2.0 ** -10) * 1.0001).all()
