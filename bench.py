@@ -327,7 +327,8 @@ def worker(args):
     counts = wrapped.get_last_stats()["token_counts"]
 
     # ---- second region: K back-to-back forwards behind one sync, HIP-event timing of the GEMM classes on
-    gemm_mask = 0b0111 | (1 << 12)  # the packed-token GEMM classes: qkv/head, fc1, fc2 (K > N), proj (K <= N)
+    # the packed-token GEMM classes: qkv/head, fc1, fc2 (K > N), proj (K <= N), and their fp8 x fp8 twins (13-15)
+    gemm_mask = 0b0111 | (1 << 12) | (0b111 << 13)
     nat.profile_reset()
     nat.profile_enable(gemm_mask)
     barrier()
