@@ -17,6 +17,10 @@ void rajni_debug_force_attention(int mode);
  * 5 = 256x128x64 3-stage persistent */
 void rajni_debug_force_gemm_tiling(int mode);
 
+/* fp8 x fp8 GEMM tiling: 0 = by shape (default), 1 = 256x128x128 always, 2 = 256x256x128 wherever it exists (bias and
+ * GELU epilogues) */
+void rajni_debug_force_f8_tiling(int mode);
+
 /* W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the plain column-fastest
  * order; -k = blocks of k column tiles regardless of size.  Results are bit-identical for every value (tested). */
 void rajni_debug_set_gemm_nblock_bytes(int bytes);

@@ -1197,10 +1197,34 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   return RAJNI_OK;
 }
 
-// fp8 x fp8 launches (gemm_f8.h): one tiling, 256 x 128 x 128, persistent
+int g_force_f8_tiling = 0;   // test hook: 0 by shape, 1 = 256 x 128 always, 2 = 256 x 256 wherever it exists
+
+// fp8 x fp8 launches (gemm_f8.h), persistent: 256 x 256 for wide outputs without a residual epilogue (QKV, FC1),
+// 256 x 128 otherwise (FC2, small problems)
 template <int EPI, bool SF32>
 int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
   const int cus = rajni_num_cus();
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU8) {
+    const bool wide_ok = p.K >= 384;
+    // measured on ViT-B at batch 256 (K = 768: 6 K steps per tile, so per-tile costs weigh double against the bf16
+    // tilings): FC1 + GELU -> e4m3 132 us on 256 x 256 vs 139 us on 256 x 128; QKV -> bf16 117 vs 105 us (its 128 KB
+    // of bf16 output per tile leave as half sectors: only 2 lanes of a 32 x 32 accumulator share a row)
+    const bool want = g_force_f8_tiling == 2 || (g_force_f8_tiling == 0 && EPI == EPI_GELU8 && p.M >= 1024 && p.N >= 1536);
+    if (wide_ok && want) {
+      p.tiles_n = (p.N + f8w::BN - 1) / f8w::BN;
+      const int tiles_m = (p.M + 255) / 256;
+      p.total_tiles = p.tiles_n * tiles_m;
+      p.nblk = n_block(p.tiles_n, tiles_m, f8w::BN, p.K, 1, cus);
+      static bool attrw[RAJNI_MAX_DEVICES] = {};
+      ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
+                     (double)p.M * p.K + (EPI == EPI_GELU8 ? 1.0 : 2.0) * (double)p.M * p.N + (double)p.N * p.K);
+      int rc;
+      if ((rc = set_lds_attr(&f8w::gemm_f8_tn_wide<EPI>, f8w::LDS_BYTES, attrw)) != RAJNI_OK) return rc;
+      hipLaunchKernelGGL((f8w::gemm_f8_tn_wide<EPI>), dim3(stream_grid(p.total_tiles, cus)), dim3(512), f8w::LDS_BYTES, s, p);
+      RAJNI_CHECK_LAUNCH("gemm_f8_tn_wide");
+      return RAJNI_OK;
+    }
+  }
   p.tiles_n = (p.N + f8::BN - 1) / f8::BN;
   const int tiles_m = (p.M + 255) / 256;
   p.total_tiles = p.tiles_n * tiles_m;
@@ -1228,6 +1252,7 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
 }  // namespace
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
+extern "C" void rajni_debug_force_f8_tiling(int mode) { g_force_f8_tiling = mode; }
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }

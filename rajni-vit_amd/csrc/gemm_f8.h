@@ -315,3 +315,274 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing (unused) DMA before LDS is released
 }
 }  // namespace f8
+
+// =============================================================================================
+// fp8 x fp8, 256(M) x 256(N) x 128(K bytes) - for wide outputs (QKV, FC1).  The 256 x 128 kernel above stages
+// 48 KB per 8.4 MFLOP and is bound by that (a K step takes ~2.1k cycles where its MFMAs need 1.0k); this tile stages
+// 64 KB per 16.8 MFLOP.  Its register budget is the bf16 wide tiling's: v_mfma_f32_32x32x64_f8f6f4 consumes 64 BYTES
+// of K per instruction, so a K step is two half steps of 64 bytes whose fragment sets (4 X + 2 W tiles x 32 bytes per
+// lane = 48 VGPRs) alternate exactly like the bf16 kernel's ks = 0 / 1 fragments; 128 accumulator registers.
+//   lane (r = lane & 31, h = lane >> 5): operand = chunks 4*ks + 2h, 4*ks + 2h + 1 of row r of the 32-row tile, for
+//   BOTH operands; C/D: column = r (the X row = output row m), row i = (reg & 3) + 8 (reg >> 2) + 4h (the W row).
+//   W tile row feeding A-row i is 16 ((i>>2)&1) + (i&3) + 4 (i>>3), which makes a lane own the 16 CONSECUTIVE
+//   output columns 16h + reg of the 32-column tile: 32-byte bf16 or 16-byte e4m3 stores per row.
+// K step j (2 LDS stages of 64 KB), registers holding the ks = 0 fragments of step j on entry:
+//   half 1: 8 MFMAs(j, ks0)  ||  12 LDS reads of (j, ks1)
+//   s_waitcnt lgkmcnt(0) vmcnt(0) ; s_barrier
+//   half 2: 8 MFMAs(j, ks1)  ||  12 LDS reads of (j+1, ks0)  ||  8 DMA pieces of step j+2 into stage j
+// Epilogues: bias -> bf16 (QKV) and bias + GELU -> e4m3 (FC1).  Host contract: K % 128 == 0, K >= 384.
+// =============================================================================================
+namespace f8w {
+using f8::Frag;
+using f8::frag_bits;
+using f8::pack4_e4m3;
+using f8::v8i;
+using wide::key_x;
+using wide::wait_step;
+constexpr int BM = 256, BN = 256, KB = 128, NS = 2;
+constexpr int X_BYTES = BM * KB, W_BYTES = BN * KB, STAGE_BYTES = X_BYTES + W_BYTES, LDS_BYTES = NS * STAGE_BYTES;
+constexpr int XP = 4, PW = 4, PIECES = XP + PW;
+constexpr int MT = 4, NT = 2;     // 32 x 32 tiles per wave: 128 rows x 64 columns
+// W tile row (of 32) read by A-row i, and the swizzle key of a W tile row: the 16 rows one ds_read_b128 lane group
+// touches ({0-3, 16-19, 4-7, 20-23} + 8 for the second group) must land in 16 distinct 16-byte slots of 256 bytes
+__device__ __forceinline__ int w_row32(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+__device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 1) * 4 + ((row >> 1) & 3); }
+
+template <int G, bool READ, bool DMA>
+__device__ __forceinline__ void sched_half() {
+  if constexpr (G < MT) {
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    if constexpr (DMA) __builtin_amdgcn_sched_group_barrier(0x020, PIECES / MT, 0);
+    sched_half<G + 1, READ, DMA>();
+  }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_GELU8, "wide fp8 tile: bias (bf16 out) or GELU (e4m3 out)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = p.total_tiles / p.tiles_n;
+  auto tile_mn = [&](int t, int& tm_, int& tn_) {   // (N block, row tile, column in block): see gemm_bf16_tn_stream
+    if (p.nblk >= p.tiles_n) { tm_ = t / p.tiles_n; tn_ = t - tm_ * p.tiles_n; return; }
+    const int per = p.nblk * tiles_m, blk = t / per, r = t - blk * per;
+    const int left = p.tiles_n - blk * p.nblk, nb = left < p.nblk ? left : p.nblk;
+    const int rr = r / nb;
+    tm_ = rr; tn_ = blk * p.nblk + (r - rr * nb);
+  };
+  const char* xp[XP];
+  const char* wp[PW];
+  const int r_in = lane >> 3, pch = lane & 7;
+  auto point_at = [&](int tile) {
+    int tm, tn;
+    tile_mn(tile, tm, tn);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int row = (wave * XP + i) * 8 + r_in;
+      int m = tm * BM + row;
+      if (m > p.M - 1) m = p.M - 1;   // clamp: duplicates are computed but never stored
+      xp[i] = reinterpret_cast<const char*>(p.X) + (long)m * p.lda + ((pch ^ key_x(row)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int row = (wave * PW + i) * 8 + r_in;    // W is allocated with its rows padded to a multiple of 256
+      wp[i] = reinterpret_cast<const char*>(p.W) + (long)(tn * BN + row) * p.ldw + ((pch ^ key_w(row)) << 4);
+    }
+  };
+  auto dma_piece = [&](int q, int k0, char* dx) {
+    if (q < XP)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xp[q] + k0), LDS_PTR(dx + (wave * XP + q) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(wp[q - XP] + k0), LDS_PTR(dx + X_BYTES + (wave * PW + q - XP) * 1024), 16, 0, 0);
+  };
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int xr0 = wm * 128 + r;                    // + 32 * mi: same key
+  const int wr0 = wn * 64 + w_row32(r);            // + 32 * ni: same key
+  int xo[2][2], wo[2][2];                          // [ks][chunk of the pair]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      xo[ks][c] = xr0 * KB + (((4 * ks + 2 * h + c) ^ key_x(xr0)) << 4);
+      wo[ks][c] = X_BYTES + wr0 * KB + (((4 * ks + 2 * h + c) ^ key_w(wr0)) << 4);
+    }
+
+  f32x16 acc[NT][MT];
+  // one half step: MFMAs on (xc, wc)  ||  if READ: fragments (stage rst, half rks) -> (xn, wn_)  ||  if DMA: K-tile dkt
+  // of the pointed-at tile -> stage dst
+  auto half = [&](auto read_c, auto dma_c, Frag (&xc)[MT], Frag (&wc)[NT], Frag (&xn)[MT], Frag (&wn_)[NT],
+                  int rst, int rks, int dkt, int dst) {
+    constexpr bool READ = decltype(read_c)::value, DMA = decltype(dma_c)::value;
+    const char* sb = smem + rst * STAGE_BYTES;
+    char* dx = smem + dst * STAGE_BYTES;
+    const int k0 = dkt * KB;
+    v8i wv[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) wv[ni] = frag_bits(wc[ni]);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const v8i xv = frag_bits(xc[mi]);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv[ni], xv, acc[ni][mi], 0, 0, 0, 0, 0, 0);
+      if constexpr (READ) {
+        xn[mi].lo = *reinterpret_cast<const bf16x8*>(sb + xo[rks][0] + mi * 32 * KB);
+        xn[mi].hi = *reinterpret_cast<const bf16x8*>(sb + xo[rks][1] + mi * 32 * KB);
+        if (mi < NT) wn_[mi].lo = *reinterpret_cast<const bf16x8*>(sb + wo[rks][0] + mi * 32 * KB);
+        else wn_[mi - NT].hi = *reinterpret_cast<const bf16x8*>(sb + wo[rks][1] + (mi - NT) * 32 * KB);
+      }
+      if constexpr (DMA) {
+#pragma unroll
+        for (int q = mi * PIECES / MT; q < (mi + 1) * PIECES / MT; ++q) dma_piece(q, k0, dx);
+      }
+    }
+    sched_half<0, READ, DMA>();
+  };
+  using T = std::true_type; using F = std::false_type;
+
+  const int nk = p.K / KB;   // >= NS + 1 (host checked)
+  int v = blockIdx.x;
+  int tile = xcd_tile_of(v, p.total_tiles);
+  Frag xa[MT], wa[NT], xb[MT], wb[NT];
+  auto read_ks0 = [&](int st) {
+    const char* sb = smem + st * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      xa[i].lo = *reinterpret_cast<const bf16x8*>(sb + xo[0][0] + i * 32 * KB);
+      xa[i].hi = *reinterpret_cast<const bf16x8*>(sb + xo[0][1] + i * 32 * KB);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      wa[i].lo = *reinterpret_cast<const bf16x8*>(sb + wo[0][0] + i * 32 * KB);
+      wa[i].hi = *reinterpret_cast<const bf16x8*>(sb + wo[0][1] + i * 32 * KB);
+    }
+  };
+  constexpr int NSTORE = EPI == EPI_GELU8 ? MT * NT : 2 * MT * NT;   // stores per wave of an interior tile's epilogue
+  bool prev_full = false;
+  point_at(tile);
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) dma_piece(q, j * KB, smem + j * STAGE_BYTES);
+  }
+  wait_step<PIECES>();   // K tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_ks0(0);
+  int st = 0;
+
+  while (true) {
+    int tm, tn;
+    tile_mn(tile, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool inter = m0 + BM <= p.M && n0 + BN <= p.N;
+    const int vn = v + gridDim.x;
+    const bool more = vn < p.total_tiles;
+    const int m_base = m0 + wm * 128, n0w = n0 + wn * 64;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float xsr[MT];
+
+    // the last K step reads no (j+1, ks0) fragments: the next tile's first fragments are read after the epilogue
+    // (one exposed LDS round trip per tile; with a fragment set live through it the epilogue's operands do not fit)
+    auto kstep = [&](auto last_c, int kt) {
+      constexpr bool LAST = decltype(last_c)::value;
+      if (kt == nk - NS && more) point_at(xcd_tile_of(vn, p.total_tiles));
+      const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
+      const int st1 = st ^ 1;
+      if constexpr (LAST) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {   // on every path (clamped): see the note on conditional loads above
+          const int m = m_base + mi * 32 + r;
+          xsr[mi] = p.xscale[m < p.M ? m : p.M - 1];
+        }
+      }
+      half(T{}, F{}, xa, wa, xb, wb, st, 1, 0, 0);
+      if (kt == 0 && prev_full) wait_step<NSTORE>();
+      else wait_step<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      using RD = std::integral_constant<bool, !LAST>;
+      half(RD{}, T{}, xb, wb, xa, wa, st1, 0, dkt, st);
+      st = st1;
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) kstep(F{}, kt);
+    kstep(T{}, nk - 1);
+
+    // ---- epilogue
+    __builtin_amdgcn_sched_barrier(0);
+    float inv[MT];
+    if constexpr (EPI == EPI_GELU8) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int m = m_base + mi * 32 + r;
+        inv[mi] = 1.0f / p.yscale[m < p.M ? m : p.M - 1];
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int c0 = n0w + 32 * ni + 16 * h;       // this lane's 16 consecutive columns of the tile
+      const bool full = c0 + 16 <= p.N;
+      float bs[16], ws[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int n = c0 + j < p.N ? c0 + j : p.N - 1;
+        bs[j] = p.bias != nullptr ? p.bias[n] : 0.f;
+        ws[j] = p.wscale[n];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on every path: see epilogue_tile
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int m = m_base + mi * 32 + r;
+        if (m >= p.M) continue;
+        float y[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) y[j] = fmaf(acc[ni][mi][j] * xsr[mi], ws[j], bs[j]);
+        if constexpr (EPI == EPI_GELU8) {
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            const f32x2 t = gelu_pk(f32x2{y[j], y[j + 1]});
+            y[j] = t[0] * inv[mi]; y[j + 1] = t[1] * inv[mi];
+          }
+          uint4 q;
+          q.x = pack4_e4m3(y[0], y[1], y[2], y[3]);   q.y = pack4_e4m3(y[4], y[5], y[6], y[7]);
+          q.z = pack4_e4m3(y[8], y[9], y[10], y[11]); q.w = pack4_e4m3(y[12], y[13], y[14], y[15]);
+          unsigned char* row = reinterpret_cast<unsigned char*>(p.Y) + (long)m * p.ldc + c0;
+          if (full) {
+            *reinterpret_cast<uint4*>(row) = q;
+          } else {
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (c0 + j < p.N) row[j] = (unsigned char)(w4[j >> 2] >> (8 * (j & 3)));
+          }
+        } else {
+          bf16_t* row = reinterpret_cast<bf16_t*>(p.Y) + (long)m * p.ldc + c0;
+          if (full) {
+            *reinterpret_cast<uint4*>(row) = pack8(y);
+            *reinterpret_cast<uint4*>(row + 8) = pack8(y + 8);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (c0 + j < p.N) row[j] = f2bf(y[j]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) read_ks0(st);      // the next tile's (K-tile 0, ks0): landed and barrier-passed in the last step
+    prev_full = inter;
+    if (!more) break;
+    v = vn;
+    tile = xcd_tile_of(v, p.total_tiles);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+}  // namespace f8w

@@ -75,8 +75,17 @@ def _f8_operands(rng, M, N, K):
     return dev(xq), dev(xs), dev(wp), dev(ws), xd, wd
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 512), (700, 768, 768), (50, 2304, 768), (1030, 200, 1024), (513, 3072, 768)])
-def test_linear_f8_bias(M, N, K):
+@pytest.fixture(params=[1, 2], ids=["256x128", "256x256"])
+def f8_tiling(request):
+    """Both fp8 x fp8 tilings (16x16x128 MFMAs on 256x128, 32x32x64 MFMAs on 256x256) must agree with fp64."""
+    nat.lib().rajni_debug_force_f8_tiling(request.param)
+    yield request.param
+    nat.lib().rajni_debug_force_f8_tiling(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 512), (700, 768, 768), (50, 2304, 768), (1030, 200, 1024), (513, 3072, 768),
+                                   (2100, 2304, 1536)])
+def test_linear_f8_bias(M, N, K, f8_tiling):
     rng = np.random.default_rng(M + N + K)
     xq, xs, wp, ws, xd, wd = _f8_operands(rng, M, N, K)
     b = rng.standard_normal(N).astype(np.float32)
@@ -87,8 +96,8 @@ def test_linear_f8_bias(M, N, K):
     assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (700, 3072, 768), (60, 1000, 1024), (1300, 520, 768)])
-def test_linear_f8_gelu_requant(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (700, 3072, 768), (60, 1000, 1024), (1300, 520, 768), (2100, 3072, 768)])
+def test_linear_f8_gelu_requant(M, N, K, f8_tiling):
     """fc1 on the fp8 pipe: bias + exact-erf GELU, output re-quantised to e4m3 with the given per-row scale."""
     rng = np.random.default_rng(M * 3 + N + K)
     xq, xs, wp, ws, xd, wd = _f8_operands(rng, M, N, K)
