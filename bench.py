@@ -165,6 +165,9 @@ def parse_args(argv=None):
                     help="JSON text or file {block: {keep_ratio, update}} (default: the README 4-stage schedule); "
                          'BASELINE configs[3] is --model vit_large_patch16_384 --batch 64 --schedule \'{"4":{"keep_ratio":0.7},'
                          '"12":{"keep_ratio":0.5},"20":{"keep_ratio":0.3}}\'')
+    ap.add_argument("--ln-fold", type=int, default=None, choices=[0, 1],
+                    help="override RAJNIViTWrapper.set_ln_fold (norm1 / norm2 as epilogue extras of the GEMMs around them); "
+                         "default: the wrapper's own default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -298,6 +301,8 @@ def worker(args):
     model = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev)
     wrapped = rajni_amd.RAJNIViTWrapper(model, schedule).eval()
     wrapped.set_weight_format(args.weight_format)
+    if args.ln_fold is not None:
+        wrapped.set_ln_fold(bool(args.ln_fold))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=gen, device=dev).to(torch.bfloat16)
     labels = torch.randint(0, cfg.num_classes, (B,), generator=gen, device=dev)
@@ -430,6 +435,7 @@ def worker(args):
                                   f"synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
                       "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}",
+                      "ln_fold": bool(wrapped._plan[1].ln_fold),
                       "collective": (f"{backend} all_reduce of [correct,total,images] (SUM) and seconds (MAX), once per run"
                                      if world > 1 else None)},
            "model_tflops": round(value * fl_img / 1e12, 1),

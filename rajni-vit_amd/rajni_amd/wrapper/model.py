@@ -24,6 +24,9 @@ from .. import ops
 from .attention import RAJNIAttention
 
 
+LN_FOLD_DEFAULT = False
+
+
 def normalise_schedule(schedule) -> Dict[int, Dict]:
     """{block index: {"keep_ratio": float, "update": bool}} with int keys.  A missing `keep_ratio`
     raises KeyError like the reference (model.py:18); `update` defaults to True (model.py:19)."""
@@ -63,7 +66,9 @@ class RAJNIViTWrapper(nn.Module):
 
         self._last_stats = None
         self._weights = None       # packed device tensors (kept alive here)
-        self._weights_key = None
+        self._weights_key = None   # epoch of the last re-pack (part of the plan key)
+        self._weights_sig = None   # [data_ptr..., _version...] of the base model's parameters at that re-pack
+        self._weights_cfg = None
         self._plan = None          # most recent (key, VitPlan, keep-alive objects, stage buffers, counts)
         self._plans = {}           # small cache by key: a ragged last batch must not evict the main plan
         self._forced: Dict[int, torch.Tensor] = {}
@@ -76,6 +81,10 @@ class RAJNIViTWrapper(nn.Module):
         self._weight_format = "model"
         # opt-in: compute the last block for the CLS row only (the head reads nothing else, model.py:65-66)
         self._cls_only_last = False
+        # norm1 / norm2 as epilogue extras of the GEMMs around them instead of kernels (`set_ln_fold`): bf16 models
+        # with the fp32 residual stream and bf16 weights
+        self._ln_fold = LN_FOLD_DEFAULT
+        self._ln_guard = None      # device int32: max over forwards of floor(|token mean| * rstd) seen by the fold
 
     # ------------------------------------------------------------------------------------------
     def get_last_stats(self):
@@ -109,6 +118,7 @@ class RAJNIViTWrapper(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("residual stream dtype must be torch.float32 or torch.bfloat16")
         self._resid_bf16 = dtype == torch.bfloat16
+        self._weights = self._weights_key = None      # (the LN fold exists on the fp32 stream only: folded copies come and go)
         self._drop_plans()
         return self
 
@@ -157,6 +167,24 @@ class RAJNIViTWrapper(nn.Module):
             self._cls_only_last = bool(on)
             self._drop_plans()
         return self
+
+    def set_ln_fold(self, on: bool = True):
+        """Run norm1 / norm2 as epilogue extras of the GEMMs around them ("LN fold"): the residual
+        epilogue of proj / fc2 also writes a bf16 copy of the stream and per-row statistics, and fc1 / the next qkv
+        compute rstd * (x W'^T - mean * colsum(W')) + b' with gamma / beta folded into W', b'.  Same function; the MFMA
+        sees bf16(x) instead of bf16(LN(x)), so a token's rounding noise grows by sqrt(1 + (mean/std)^2) - read
+        `ln_fold_guard()` after a forward for the largest |mean|/std met.  bf16 models, fp32 residual stream, "model"
+        weight format; silently inactive otherwise."""
+        if bool(on) != self._ln_fold:
+            self._ln_fold = bool(on)
+            self._weights = self._weights_key = None
+            self._drop_plans()
+        return self
+
+    def ln_fold_guard(self) -> int:
+        """Largest floor(|mean| * rstd) over the tokens of every folded LayerNorm since the last reset (0 when the fold
+        is inactive): the factor by which the fold amplified bf16 rounding for the worst token.  Synchronises."""
+        return 0 if self._ln_guard is None else int(self._ln_guard.item())
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
@@ -242,11 +270,22 @@ class RAJNIViTWrapper(nn.Module):
         self._param_list = [p for p in self.m.parameters()]
         return self._param_list
 
+    def _fold_active(self, dtype, desc) -> bool:
+        return (self._ln_fold and dtype == torch.bfloat16 and not self._resid_bf16 and self._weight_format == "model"
+                and desc["C"] % 64 == 0 and desc["hidden"] % 64 == 0)
+
     def _pack_weights(self, device, dtype):
         params = self._all_params()
-        key = (str(device), dtype, self._weight_format) + tuple((p.data_ptr(), p._version) for p in params)
-        if self._weights_key == key:
+        # fingerprint of the live weights: storage pointers (`.to()`, `param.data = ...`) and version counters (in-place
+        # edits, load_state_dict) - two flat list comprehensions and one C-speed list compare per forward (this sits in
+        # the sync -> forward -> sync metric); `_weights_key` is just the epoch of the last re-pack
+        sig = [p.data_ptr() for p in params]
+        sig += [p._version for p in params]
+        cfg_key = (device, dtype, self._weight_format)
+        if self._weights is not None and self._weights_sig == sig and self._weights_cfg == cfg_key:
             return self._weights
+        key = (getattr(self, "_weights_epoch", 0) + 1)
+        self._weights_epoch = key
         desc = self._describe()
         m = self.m
         fp8 = self._weight_format in ("fp8", "fp8_mfma")
@@ -266,6 +305,8 @@ class RAJNIViTWrapper(nn.Module):
         W["head_w"] = pw(m.head.weight)
         W["head_b"] = pv(m.head.bias) if m.head.bias is not None else zeros(desc["num_classes"])
         blocks = []
+        fold = self._fold_active(dtype, desc)
+        W["ln_fold"] = fold
         for blk in self.blocks:
             a = blk.attn
             ls1 = getattr(blk, "ls1", None)
@@ -300,6 +341,16 @@ class RAJNIViTWrapper(nn.Module):
                 ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
                 fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=fc1_b,
                 fc2_w=fc2_w, fc2_s=fc2_s, fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
+            if fold:
+                # gamma / beta of norm2 folded into fc1, and of norm1 into qkv (block 0's norm1 follows the patch
+                # embed, not a residual epilogue: it stays a kernel)
+                blocks[-1]["fc1_wf"], blocks[-1]["fc1_bf"], blocks[-1]["fc1_cs"] = ops.fold_layernorm(
+                    blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.norm2.weight, blk.norm2.bias, dtype, device)
+                if hpad != hid:
+                    raise NotImplementedError("ln fold with an MLP width that is not a multiple of 64")
+                if len(blocks) > 1:
+                    blocks[-1]["qkv_wf"], blocks[-1]["qkv_bf"], blocks[-1]["qkv_cs"] = ops.fold_layernorm(
+                        a.qkv.weight, a.qkv.bias, blk.norm1.weight, blk.norm1.bias, dtype, device)
             if self._weight_format == "fp8_mfma":
                 # constants of the hidden-activation bound (rajni_layernorm_fp8): largest row norm of the DEQUANTISED
                 # fc1 weight and largest |bias| as the kernels hold it
@@ -308,13 +359,14 @@ class RAJNIViTWrapper(nn.Module):
                 blocks[-1]["fc1_bias_absmax"] = float(fc1_b.abs().max())
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
+        self._weights_sig, self._weights_cfg = sig, cfg_key
         self._drop_plans()
         return W
 
     def _build_plan(self, B: int, S: int, device, dtype):
         W = self._pack_weights(device, dtype)
         d = W["desc"]
-        key = (B, S, str(device), dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16,
+        key = (B, S, device, dtype, self._weights_key, tuple(sorted(self._forced)), self._trace_scores, self._resid_bf16,
                self._cls_only_last)
         if self._plan is not None and self._plan[0] == key:
             return self._plan
@@ -342,6 +394,8 @@ class RAJNIViTWrapper(nn.Module):
                 setattr(cb, name, nat.ptr(bw[name]))
             if self._weight_format == "fp8_mfma":
                 cb.fc1_rownorm_max, cb.fc1_bias_absmax = bw["fc1_rownorm_max"], bw["fc1_bias_absmax"]
+            for name in ("qkv_wf", "qkv_bf", "qkv_cs", "fc1_wf", "fc1_bf", "fc1_cs"):
+                setattr(cb, name, nat.ptr(bw.get(name)))
             if i in self.pruning_schedule:
                 cfg = self.pruning_schedule[i]
                 N = counts[i]
@@ -381,6 +435,11 @@ class RAJNIViTWrapper(nn.Module):
         plan.resid_bf16 = int(self._resid_bf16)
         plan.cls_only_last_block = int(self._cls_only_last)
         plan.act_fp8 = int(self._weight_format == "fp8_mfma")
+        plan.ln_fold = int(bool(W.get("ln_fold")))
+        if plan.ln_fold:
+            if self._ln_guard is None or self._ln_guard.device != torch.device(device):
+                self._ln_guard = torch.zeros(1, dtype=torch.int32, device=device)
+            plan.ln_guard = self._ln_guard.data_ptr()
         nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes

@@ -17,22 +17,27 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def kernel_id(mangled):
-    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, TAG> -> tuple of ints"""
+    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, TAG, LNF> -> tuple of ints"""
     m = re.search(r"gemm_bf16_tn_streamI(.*?)EEv", mangled)
+    if m is None:          # the fp8 x fp8 kernels: <EPI, SF32, TAG> / <EPI>; every instantiation is dispatched
+        m = re.search(r"gemm_f8_tn_(?:stream|wide)I(.*?)EEv", mangled)
+        return ("f8",) + tuple(int(x[2:]) for x in re.findall(r"L[ib]\d+", m.group(1)))
     return tuple(int(x[2:]) for x in re.findall(r"L[ib]\d+", m.group(1)))
 
 
 def dispatched(k):
     """instantiations launch_gemm picks without a test hook: everything except the 256x256 tiling with the
     fused patch loader (a patch embed wider than 1536 channels has K = 3*14*14, not a multiple of 64)."""
-    epi, aload, sf32, wm, wn, mi, ns, w8, tag = k
+    if k[0] == "f8":
+        return True
+    epi, aload, sf32, wm, wn, mi, ns, w8, tag, lnf = k
     return not ((wm, wn, mi, ns) == (2, 4, 8, 2) and aload == 1)
 
 
 def scan(asm_path):
     rows, name = [], None
     for line in open(asm_path):
-        m = re.match(r"^(_ZN\S*gemm_bf16_tn_stream\S*):", line)
+        m = re.match(r"^(_ZN\S*gemm_(?:bf16_tn_stream|f8_tn_stream|f8_tn_wide)\S*):", line)
         if m:
             name, inner, drains, scratch, spills = m.group(1), False, 0, 0, None
             continue
@@ -61,7 +66,7 @@ def main():
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         rows = scan(out)
     bad = 0
-    for k, drains, scratch, spills in sorted(rows):
+    for k, drains, scratch, spills in sorted(rows, key=lambda r: tuple(map(str, r[0]))):
         prod = dispatched(k)
         ok = (drains == 0 and scratch == 0 and spills == 0) or not prod
         bad += not ok
