@@ -168,6 +168,9 @@ def parse_args(argv=None):
     ap.add_argument("--ln-fold", type=int, default=None, choices=[0, 1],
                     help="override RAJNIViTWrapper.set_ln_fold (norm1 / norm2 as epilogue extras of the GEMMs around them); "
                          "default: the wrapper's own default")
+    ap.add_argument("--residual", default="fp32", choices=["fp32", "bf16"],
+                    help="residual stream precision between blocks (RAJNIViTWrapper.set_residual_dtype): fp32 (default, the "
+                         "build's accuracy choice) or bf16 (what the reference's own bf16 model keeps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -303,6 +306,8 @@ def worker(args):
     wrapped.set_weight_format(args.weight_format)
     if args.ln_fold is not None:
         wrapped.set_ln_fold(bool(args.ln_fold))
+    if args.residual == "bf16":
+        wrapped.set_residual_dtype(torch.bfloat16)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=gen, device=dev).to(torch.bfloat16)
     labels = torch.randint(0, cfg.num_classes, (B,), generator=gen, device=dev)
@@ -370,7 +375,7 @@ def worker(args):
     peak_tflops = PEAK_FP8_TFLOPS if fp8_mfma else PEAK_BF16_TFLOPS
     # BASELINE.json's metric is quoted on this workload; other --model/--schedule/--batch runs are labelled as such
     headline_workload = (args.model == "vit_base_patch16_224" and not args.schedule and args.batch == 256
-                         and args.weight_format == "model")
+                         and args.weight_format == "model" and args.residual == "fp32" and not args.ln_fold)
     roofline = None
     if prof:
         # dominant kernel = the GEMM instantiation with the most time
@@ -435,7 +440,7 @@ def worker(args):
                                   f"synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
                       "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}",
-                      "ln_fold": bool(wrapped._plan[1].ln_fold),
+                      "ln_fold": bool(wrapped._plan[1].ln_fold), "residual_stream": args.residual,
                       "collective": (f"{backend} all_reduce of [correct,total,images] (SUM) and seconds (MAX), once per run"
                                      if world > 1 else None)},
            "model_tflops": round(value * fl_img / 1e12, 1),
@@ -458,6 +463,15 @@ def worker(args):
             wrapped(images)
         out["cls_only_last_block_images_per_sec"] = round(metric_run(wrapped, args.steps), 1)
         wrapped.set_last_block_cls_only(False)
+        if args.residual == "fp32":
+            # second opt-in, NOT part of `value` either: the residual stream kept in bf16 between blocks, as the
+            # reference's own bf16 model keeps it (costs ~1e-2 of the logit scale against the fp32 reference, DESIGN.md
+            # section 2; `value` runs the fp32 stream)
+            wrapped.set_residual_dtype(torch.bfloat16)
+            for _ in range(3):
+                wrapped(images)
+            out["bf16_residual_stream_images_per_sec"] = round(metric_run(wrapped, args.steps), 1)
+            wrapped.set_residual_dtype(torch.float32)
     if world == 1 and not args.no_torch_baseline:
         # the "4x" denominator: unpruned timm-shaped base, stock PyTorch-ROCm ops, same batch, same harness
         base = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev).eval()
