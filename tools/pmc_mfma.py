@@ -25,7 +25,7 @@ COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA
 
 def clean(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    if re.search(r"gemm_(?:bf16|f8)_tn_stream<2,.*, 1>\(", name):
+    if re.search(r"gemm_bf16_tn_stream<2,.*, 1, (?:true|false)>\(", name):
         name += " [proj]"
     return name
 
@@ -47,8 +47,12 @@ def main():
         for c in COUNTERS:
             k[c] += d.get(c, 0.0)
         m = re.search(r"gemm_bf16_tn_(?:stream|128x128)<(\d)", name)
-        if m:
-            cls = RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
+        m8 = re.search(r"gemm_f8_tn_(?:stream|wide)<(\d)", name)
+        if m or m8:
+            if m8:
+                cls = {0: "gemm_f8_tn<bias>", 4: "gemm_f8_tn<bias,gelu,requant>", 2: "gemm_f8_tn<bias,ls,resid>"}[int(m8.group(1))]
+            else:
+                cls = RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
             c2 = by_class.setdefault(cls, {"launches": 0, **{c: 0.0 for c in COUNTERS}})
             c2["launches"] += 1
             for c in COUNTERS:

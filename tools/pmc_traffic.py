@@ -26,7 +26,7 @@ def per_kernel(db_path, counter):
     out = {}
     for name, v in rows:
         name = re.sub(r"\(anonymous namespace\)::", "", name)
-        if re.search(r"gemm_bf16_tn_stream<2,.*, 1>\(", name):
+        if re.search(r"gemm_bf16_tn_stream<2,.*, 1, (?:true|false)>\(", name):
             name += " [proj]"
         c, t = out.get(name, (0, 0.0))
         out[name] = (c + 1, t + v)
@@ -44,8 +44,12 @@ def main():
         f_mb, w_mb = 2.0 * kib * 1024 / n / 1e6, wkib * 1024 / wn / 1e6
         by_kernel[name] = {"launches": n, "fetch_MB_corrected": round(f_mb, 1), "write_MB": round(w_mb, 1)}
         m = re.search(r"gemm_bf16_tn_(?:stream|128x128)<(\d)", name)
-        if m:
-            cls = RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
+        m8 = re.search(r"gemm_f8_tn_(?:stream|wide)<(\d)", name)
+        if m or m8:
+            if m8:
+                cls = {0: "gemm_f8_tn<bias>", 4: "gemm_f8_tn<bias,gelu,requant>", 2: "gemm_f8_tn<bias,ls,resid>"}[int(m8.group(1))]
+            else:
+                cls = RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
             c = by_class.setdefault(cls, {"launches": 0, "f": 0.0, "w": 0.0})
             c["launches"] += n; c["f"] += f_mb * n; c["w"] += w_mb * n
     out = {"note": __doc__.split("\n\n")[-1].replace("\n", " "),
