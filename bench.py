@@ -399,13 +399,14 @@ def worker(args):
         # every GEMM class here is priced against the MFMA roof except the attention projection (K <= N),
         # whose 2 x M x N x 4 bytes of fp32 residual stream make it HBM bound (AI ~ 150 flop/B < the ~310 ridge)
         hbm_bound = "K<=N" in name
+        kpeak = PEAK_FP8_TFLOPS if name.startswith("gemm_f8") else PEAK_BF16_TFLOPS    # the pipe THIS kernel runs on
         gbps = rec["bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
         rel = lambda pth: os.path.relpath(pth, ROOT) if pth else None
         roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
                     "achieved": round(gbps, 1) if hbm_bound else round(achieved, 1),
-                    "peak": PEAK_HBM_GBS if hbm_bound else peak_tflops,
+                    "peak": PEAK_HBM_GBS if hbm_bound else kpeak,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / peak_tflops, 4),
+                    "frac": round(gbps / PEAK_HBM_GBS, 4) if hbm_bound else round(achieved / kpeak, 4),
                     "traffic": traffic,
                     "traffic_source": (rel(traffic_src) + " (rocprofv3 PMC, separate passes)") if traffic else None,
                     "mfma_busy_frac": mfma_busy,

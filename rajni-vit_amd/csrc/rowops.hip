@@ -120,8 +120,10 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
   const float inv = 1.0f / scale;
   unsigned char* yr = yq + (long)row * C;
+  int plo[LN_MAX_CHUNKS], phi[LN_MAX_CHUNKS];
 #pragma unroll
   for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    plo[i] = phi[i] = 0;
     const int c = lane + i * 64;
     if (c < nchunk) {
       float q[8];
@@ -131,7 +133,18 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
       int hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
       hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
-      *reinterpret_cast<uint2*>(yr + c * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+      plo[i] = lo; phi[i] = hi;
+    }
+  }
+  // 16-byte stores: an even lane takes its odd neighbour's 8 bytes (adjacent chunks) - with 8-byte stores a wave
+  // instruction wrote half sectors
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    const int nlo = __shfl_down(plo[i], 1, 64), nhi = __shfl_down(phi[i], 1, 64);
+    if (c < nchunk && (lane & 1) == 0) {
+      if (c + 1 < nchunk) *reinterpret_cast<uint4*>(yr + c * 8) = make_uint4((unsigned)plo[i], (unsigned)phi[i], (unsigned)nlo, (unsigned)nhi);
+      else *reinterpret_cast<uint2*>(yr + c * 8) = make_uint2((unsigned)plo[i], (unsigned)phi[i]);
     }
   }
   if (lane == 0) {
