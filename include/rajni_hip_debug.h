@@ -21,6 +21,10 @@ void rajni_debug_force_gemm_tiling(int mode);
  * GELU epilogues) */
 void rajni_debug_force_f8_tiling(int mode);
 
+/* every other workgroup of an XCD sleeps `units` x 8192 cycles before its first tile of a residual-epilogue GEMM, so
+ * that the two halves of the chip do not burst in the same instant; default 2 (+0.5-0.8 % on the forward), 0 = off */
+void rajni_debug_set_resid_stagger(int units);
+
 /* W bytes one N block of the persistent tile order may occupy (default 1600 KiB); 0 = the plain column-fastest
  * order; -k = blocks of k column tiles regardless of size.  Results are bit-identical for every value (tested). */
 void rajni_debug_set_gemm_nblock_bytes(int bytes);

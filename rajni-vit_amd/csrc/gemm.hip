@@ -57,6 +57,8 @@ struct GemmParams {
   int cin, S, log2ps, gw, npatch;
   const void* pos; int pos_off; // pos-embed rows, activation dtype
   unsigned long long* stamps;   // diagnostic builds only (RAJNI_GEMM_STAMPS): 4 s_memtime values per block
+  int stagger;                  // residual launches: every other workgroup of an XCD sleeps stagger x 8k cycles before its
+                                // first tile (see g_resid_stagger); 0 = off
 };
 
 // exact-erf GELU (timm nn.GELU()) for the bf16 path, two values per instruction (v_pk_*_f32, no
@@ -808,6 +810,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
   int tile = xcd_tile_of(v, p.total_tiles);
   bf16x8 xa[MI], xb[MI];
   WFrag wa[NI], wb[NI];
+  if constexpr (EPI == EPI_RESID) {
+    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   constexpr int WBASE = (NS - 2) * C::PIECES;
   auto interior = [&](int t) {   // a tile whose 256 rows and BN columns all exist
@@ -1260,9 +1266,16 @@ inline bool wide_wins_on_rounds(int M, int N, int cus) {
 // the 20 GEMM shapes of the schedule.
 inline int stream_grid(int total_tiles, int cus) { return total_tiles <= cus ? total_tiles : cus; }
 
+// Every other workgroup of an XCD starts a residual-epilogue launch 2 x 8192 cycles late, so that the two halves of the
+// chip do not hit their prologue loads and epilogue bursts in the same instant.  Measured (tools/stagger_probe.py,
+// tools/ab_forward.py stagger): proj alone -4 % at 1 unit and worse from 2 on, fc2 alone flat; in the forward 2 units
+// are best: 9.09 -> 9.03 ms (+0.5-0.8 %), 4 units neutral, 6 units -1.2 %.  rajni_debug_set_resid_stagger(0) turns it off.
+int g_resid_stagger = 2;
+
 template <int EPI, int ALOAD, bool SF32, bool W8 = false, bool LNF = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.stamps = rajni_g_stamps;
+  p.stagger = g_resid_stagger;
   p.tiles_n = (p.N + 127) / 128;
   const int t256 = p.tiles_n * ((p.M + 255) / 256), t128 = p.tiles_n * ((p.M + 127) / 128);
   int mode = g_force_tiling;
@@ -1383,6 +1396,7 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
 
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 extern "C" void rajni_debug_force_f8_tiling(int mode) { g_force_f8_tiling = mode; }
+extern "C" void rajni_debug_set_resid_stagger(int units) { g_resid_stagger = units; }
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }

@@ -84,6 +84,7 @@ _SIGS = {
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "rajni_debug_force_gemm_tiling": (None, [c_int]),
     "rajni_debug_force_f8_tiling": (None, [c_int]),
+    "rajni_debug_set_resid_stagger": (None, [c_int]),
     "rajni_debug_set_gemm_nblock_bytes": (None, [c_int]),
     "rajni_debug_force_attention": (None, [c_int]),
     "rajni_debug_force_score_two_pass": (None, [c_int]),
