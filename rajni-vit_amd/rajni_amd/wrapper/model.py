@@ -463,11 +463,28 @@ class RAJNIViTWrapper(nn.Module):
         x = x.contiguous()
         B, S = x.shape[0], x.shape[-1]
         with nat.device_guard(x.device):
-            _, plan, keep_alive, _, counts = self._build_plan(B, S, x.device, dtype)
-            ld = plan.logits_ld
-            logits = torch.empty((B, ld), dtype=dtype, device=x.device)
-            nat.check(nat.lib().rajni_vit_forward(C.byref(plan), x.data_ptr(), logits.data_ptr(),
-                                                  nat.stream_ptr(x.device)), "rajni_vit_forward")
-        tc = keep_alive[1]
+            def launch(entry):
+                plan = entry[1]
+                out = torch.empty((B, plan.logits_ld), dtype=dtype, device=x.device)
+                nat.check(nat.lib().rajni_vit_forward(C.byref(plan), x.data_ptr(), out.data_ptr(),
+                                                      nat.stream_ptr(x.device)), "rajni_vit_forward")
+                return out
+            # Optimistic launch: with a plan of this batch shape at hand the kernels are enqueued FIRST and the check
+            # that the base model's weights are still the packed ones (a walk over ~150 parameters, ~0.1 ms of Python)
+            # runs while the GPU works - in the sync -> forward -> sync metric of evaluate_model that check would
+            # otherwise sit in front of every forward.  Packed weights are copies, so a launch on a stale plan reads
+            # consistent (old) data; if the check finds a change the forward is simply enqueued again on the new plan
+            # and the first result is dropped.  Option setters drop `_plan`, so they always take the slow path.
+            cached = self._plan
+            if cached is not None and cached[0][:4] == (B, S, x.device, dtype):
+                logits = launch(cached)
+                entry = self._build_plan(B, S, x.device, dtype)
+                if entry is not cached:
+                    logits = launch(entry)
+            else:
+                entry = self._build_plan(B, S, x.device, dtype)
+                logits = launch(entry)
+        plan, tc = entry[1], entry[2][1]
         self._last_stats = {"token_counts": [int(tc[i]) for i in range(plan.depth)]}   # model.py:68
+        ld = plan.logits_ld
         return logits[:, : plan.num_classes] if ld != plan.num_classes else logits
