@@ -344,7 +344,11 @@ __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int
         }
     }
   }
-  if constexpr (LNF && EPI == EPI_RESID) ln_fold_row(p, orow, n0w, g, v);   // host: N % 64 == 0, so every column exists
+  if constexpr (LNF && EPI == EPI_RESID) {
+    // host: N % 64 == 0, so a wave's 64-column block lies wholly inside the output or wholly past it (N = 192 on 128-wide
+    // tiles: the second tile's upper half; found by tools/fuzz_linear_r2.py - it wrote into the next row's copy)
+    if (n0w < p.N) ln_fold_row(p, orow, n0w, g, v);
+  }
 }
 
 // Residual rows of a tile, loaded EARLY (during the last K step) for the fp32-stream RESID epilogue:

@@ -17,6 +17,15 @@ def test_linear_fuzz_against_torch():
     assert mod.run(cases=250, seed=2026, verbose=False) == 0
 
 
+def test_linear_fuzz_round2_forms_against_torch():
+    """fp8 x fp8 launches (both tilings, every epilogue, ragged shapes, M from 1 up) and the LayerNorm-fold producer /
+    consumer pair (tools/fuzz_linear_r2.py)."""
+    spec = importlib.util.spec_from_file_location("fuzz_linear_r2", os.path.join(ROOT, "tools", "fuzz_linear_r2.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(cases=150, seed=2026, verbose=False) == 0
+
+
 def test_attention_and_selection_fuzz_against_torch():
     spec = importlib.util.spec_from_file_location("fuzz_attention", os.path.join(ROOT, "tools", "fuzz_attention.py"))
     mod = importlib.util.module_from_spec(spec)
