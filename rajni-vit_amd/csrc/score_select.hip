@@ -18,6 +18,9 @@ namespace {
 #define RAJNI_SS_THREADS 1024
 #endif
 constexpr int SS_THREADS = RAJNI_SS_THREADS;
+// threads (and LDS floats) of the token-mean partial sums: 512 like the 8-wave version of the kernel, so that the
+// 16-wave one needs no more LDS (N = 589 with 16 heads still fits 160 KiB) and sums in the same fixed order
+constexpr int SS_PART = 512;
 #ifndef RAJNI_SS_KU
 #define RAJNI_SS_KU 8   // K-pass chunks in flight per lane
 #endif
@@ -77,8 +80,8 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   float* acls = region + region_sz;    // [N]
   float* sc = acls + N;                // vnorm [N] then scores [N]
   float* hstat = sc + N;               // [2H]
-  float* part = hstat + 2 * H;         // [SS_THREADS]
-  float* mean = part + SS_THREADS;     // [D]
+  float* part = hstat + 2 * H;         // [SS_PART]
+  float* mean = part + SS_PART;        // [D]
   float* misc = mean + D;              // [16]
   int* wcount = reinterpret_cast<int*>(misc + 16);  // [SS_THREADS / 64]
 
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     SS_STAMP(3);
     // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
     {
-      const int d = tid % D, prt = tid / D, nparts = SS_THREADS / D;   // threads past nparts * D idle
+      const int d = tid % D, prt = tid / D, nparts = SS_PART / D;      // threads past nparts * D idle
       float s = 0.f;
       for (int n = prt < nparts ? prt : N; n < N; n += nparts) s += vbar[n * D + d];
       if (prt < nparts) part[prt * D + d] = s;
@@ -406,7 +409,7 @@ size_t ss_lds_bytes(int N, int H, int D, bool merged) {
   const size_t C = (size_t)H * D;
   const size_t region = merged ? (size_t)((H * N + 3) & ~3) + (size_t)N * D
                                : (size_t)((((H * N > N * D) ? H * N : N * D) + 3) & ~3);
-  return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_THREADS + D + 16 + SS_THREADS / 64) * sizeof(float);
+  return (C + region + 2 * (size_t)N + 2 * (size_t)H + SS_PART + D + 16 + SS_THREADS / 64) * sizeof(float);
 }
 
 int g_ss_force_two_pass = 0;   // test hook (rajni_hip_debug.h): 1 = the two-pass layout even when the merged one fits
