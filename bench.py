@@ -100,7 +100,7 @@ def cpu_baseline(cfg, schedule, seconds_budget=20.0):
                       f"(usable cores of {os.cpu_count()} logical), {dt:.1f} s"}
 
 
-def reference_agreement(dev, name="base224_agree256", chunk=64):
+def reference_agreement(dev, name="base224_agree256", chunk=64, weight_format="model", residual="fp32"):
     """"top-1 delta vs the reference wrapper" with resolution.  There are no trained weights or labels here, so the
     statement is agreement with the REFERENCE'S OWN OUTPUTS on a committed fixture (tests/golden/make_golden.py
     agreement_case): 256 seeded images, ViT-B/16 dims, README schedule, seeded weights; the reference's fp32 CPU
@@ -117,6 +117,9 @@ def reference_agreement(dev, name="base224_agree256", chunk=64):
         fx = ts.create_model(ts.CONFIGS[meta["cfg_name"]], seed=meta["seed"], std=meta["std"],
                              bias_std=meta["bias_std"], round_bf16=True)
         fw = rajni_amd.RAJNIViTWrapper(fx, meta["schedule"]).to(dev).to(torch.bfloat16).eval()
+        fw.set_weight_format(weight_format)
+        if residual == "bf16":
+            fw.set_residual_dtype(torch.bfloat16)
         images = torch.from_numpy(case_images(meta, data))
         ref = data["logits"]
         n = ref.shape[0]
@@ -138,6 +141,7 @@ def reference_agreement(dev, name="base224_agree256", chunk=64):
 
         inj, free = run(True), run(False)
         out = {"fixture": f"tests/golden/{name} (reference fp32 CPU run, ViT-B/16 dims, README schedule, seeded weights)",
+               "build_options": {"weight_format": weight_format, "residual_stream": residual},
                "images": int(n), "logit_scale": round(scale, 4),
                "median_top2_margin": round(float(meta.get("median_top2_margin", float("nan"))), 4),
                "injected_selections": cmp(inj), "free_running": cmp(free),
@@ -448,8 +452,10 @@ def worker(args):
            "model_mfma_frac": round(value * fl_img / 1e12 / (peak_tflops * world), 4),
            "roofline": roofline}
 
-    if headline_workload and world == 1 and not args.no_torch_baseline:   # (skipped with the other side runs when profiling:
-        out["reference_agreement"] = reference_agreement(dev)             #  its 64-image forwards would skew per-kernel averages)
+    vitb_workload = args.model == "vit_base_patch16_224" and not args.schedule and not args.ln_fold
+    if vitb_workload and world == 1 and not args.no_torch_baseline:   # (skipped with the other side runs when profiling:
+        # its 64-image forwards would skew per-kernel averages); for the opt-in formats it prices their numerics contract
+        out["reference_agreement"] = reference_agreement(dev, weight_format=args.weight_format, residual=args.residual)
     if hbm_kernels:
         # algorithmic bytes: score+select reads the K and V thirds of qkv once ((2NC + C) x 2 B per image) and writes
         # indices/scores; attention reads the kept q, k, v rows through keep_idx and writes the output (the
