@@ -214,7 +214,7 @@ def test_forward_fp8_mfma_single_block_is_tight():
     assert err <= 0.5 * cost + 1e-2 * scale
 
 
-@pytest.mark.parametrize("name", ["base224_fp32", "deit3_fp32"])
+@pytest.mark.parametrize("name", ["base224_fp32", "deit3_fp32", "large384_fp32"])
 def test_forward_fp8_mfma_fixtures(name):
     """ViT-B / DeiT-3-B dims (configs[4]'s model) on the reference fixtures, the reference's selections injected:
     against the oracle on dequantised operands with the rule, and the reported cost of the whole quantisation (weights
