@@ -44,6 +44,11 @@ def get_args(argv=None):
     p.add_argument("--weights", type=str, default=None, help="local timm-format state dict (.safetensors / .pt)")
     p.add_argument("--pretrained", action="store_true", help="timm pretrained weights (needs timm + network)")
     p.add_argument("--seed", type=int, default=0)
+    # build-specific opt-ins (none of them exists in the reference CLI; defaults = the reference-faithful path)
+    p.add_argument("--weight_format", type=str, default="model", choices=["model", "fp8", "fp8_mfma"],
+                   help="RAJNIViTWrapper.set_weight_format: e4m3 block weights (fp8) / plus e4m3 activations on the fp8 matrix pipe (fp8_mfma)")
+    p.add_argument("--residual", type=str, default="float32", choices=["float32", "bfloat16"],
+                   help="residual stream precision between blocks (RAJNIViTWrapper.set_residual_dtype)")
     return p.parse_args(argv)
 
 
@@ -177,6 +182,10 @@ def main(argv=None):
     # the wrapper mutates its base in place (reference model.py:16-21): wrap a second model
     base2, _ = create_base(args)
     model = RAJNIViTWrapper(base2.to(dtype), schedule).to(device).eval()
+    if args.weight_format != "model":
+        model.set_weight_format(args.weight_format)
+    if args.residual == "bfloat16":
+        model.set_residual_dtype(torch.bfloat16)
     say("Evaluating RAJNI model (HIP path)...")
     acc, thr = evaluate_model(model, loader, device=device, max_batches=args.max_batches, warmup=args.warmup)
     say(f"RAJNI accuracy: {acc:.2f}%  throughput: {thr:.1f} img/s")
