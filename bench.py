@@ -169,9 +169,6 @@ def parse_args(argv=None):
                     help="JSON text or file {block: {keep_ratio, update}} (default: the README 4-stage schedule); "
                          'BASELINE configs[3] is --model vit_large_patch16_384 --batch 64 --schedule \'{"4":{"keep_ratio":0.7},'
                          '"12":{"keep_ratio":0.5},"20":{"keep_ratio":0.3}}\'')
-    ap.add_argument("--ln-fold", type=int, default=None, choices=[0, 1],
-                    help="override RAJNIViTWrapper.set_ln_fold (norm1 / norm2 as epilogue extras of the GEMMs around them); "
-                         "default: the wrapper's own default")
     ap.add_argument("--residual", default="fp32", choices=["fp32", "bf16"],
                     help="residual stream precision between blocks (RAJNIViTWrapper.set_residual_dtype): fp32 (default, the "
                          "build's accuracy choice) or bf16 (what the reference's own bf16 model keeps)")
@@ -308,8 +305,6 @@ def worker(args):
     model = ts.create_model(cfg, seed=0).to(torch.bfloat16).to(dev)
     wrapped = rajni_amd.RAJNIViTWrapper(model, schedule).eval()
     wrapped.set_weight_format(args.weight_format)
-    if args.ln_fold is not None:
-        wrapped.set_ln_fold(bool(args.ln_fold))
     if args.residual == "bf16":
         wrapped.set_residual_dtype(torch.bfloat16)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -379,7 +374,7 @@ def worker(args):
     peak_tflops = PEAK_FP8_TFLOPS if fp8_mfma else PEAK_BF16_TFLOPS
     # BASELINE.json's metric is quoted on this workload; other --model/--schedule/--batch runs are labelled as such
     headline_workload = (args.model == "vit_base_patch16_224" and not args.schedule and args.batch == 256
-                         and args.weight_format == "model" and args.residual == "fp32" and not args.ln_fold)
+                         and args.weight_format == "model" and args.residual == "fp32")
     roofline = None
     if prof:
         # dominant kernel = the GEMM instantiation with the most time
@@ -445,14 +440,14 @@ def worker(args):
                                   f"synthetic randn 3x{cfg.img_size}x{cfg.img_size}, "
                                   "random-init weights (seed 0)",
                       "global_batch": world * B, "token_counts": counts, "parallelism": f"dp{world}",
-                      "ln_fold": bool(wrapped._plan[1].ln_fold), "residual_stream": args.residual,
+                      "residual_stream": args.residual,
                       "collective": (f"{backend} all_reduce of [correct,total,images] (SUM) and seconds (MAX), once per run"
                                      if world > 1 else None)},
            "model_tflops": round(value * fl_img / 1e12, 1),
            "model_mfma_frac": round(value * fl_img / 1e12 / (peak_tflops * world), 4),
            "roofline": roofline}
 
-    vitb_workload = args.model == "vit_base_patch16_224" and not args.schedule and not args.ln_fold
+    vitb_workload = args.model == "vit_base_patch16_224" and not args.schedule
     if vitb_workload and world == 1 and not args.no_torch_baseline:   # (skipped with the other side runs when profiling:
         # its 64-image forwards would skew per-kernel averages); for the opt-in formats it prices their numerics contract
         out["reference_agreement"] = reference_agreement(dev, weight_format=args.weight_format, residual=args.residual)

@@ -46,7 +46,7 @@ enum {
                               model.py:59 (mlp.fc2, ls2, add)                                       */
 };
 
-#define RAJNI_ABI_VERSION 6 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
+#define RAJNI_ABI_VERSION 7 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
 int rajni_abi_version(void); /* == RAJNI_ABI_VERSION of the header the library was built from */
 const char* rajni_last_error(void);
 /* 0 when a gfx950 device is usable by this process, else an error code (message in last_error) */
@@ -99,14 +99,6 @@ int rajni_layernorm(const void* x, long x_row_stride, const float* w, const floa
  *   hid_scale[r] = (1.0625 * ||ln(x)[r]||_2 * w1_rownorm_max + b1_absmax) / 448   (1 when that is 0);
  * e4m3 is a floating-point format, so a bound a few binades above the true maximum costs no precision.
  * x is fp32 when x_f32 != 0, else bf16.  C % 8 == 0, C <= 2048. */
-/* LN fold, middle step: per row, combine the `nblocks` (mean, M2) pairs a producer launch wrote (blocks of 64 columns;
- * Chan's parallel-variance formula: exact in any |mean| / std regime) into stats[row] = (mean, 1 / sqrt(var + eps)),
- * var = M2 / (64 nblocks).  guard (int32, device, may be NULL) receives atomicMax of floor(|mean| * rstd) over the
- * rows: how many standard deviations the worst token's mean sits from zero - the factor by which the fold amplifies
- * the bf16 rounding of that token's activations. */
-int rajni_ln_stats(const float* partials, float* stats, int rows, int nblocks, float eps, int32_t* guard,
-                   rajni_stream_t stream);
-
 int rajni_layernorm_fp8(const void* x, long x_row_stride, const float* w, const float* b, void* y_q,
                         float* y_scale, float* hid_scale, float w1_rownorm_max, float b1_absmax,
                         int rows, int C, float eps, int x_f32, rajni_stream_t stream);
@@ -140,19 +132,6 @@ typedef struct {
    * (ldc in bytes, % 16 == 0) holding e4m3_rne_sat(gelu(.) * (1 / y_scale[m])) - the next linear's x / x_scale. */
   const float* x_scale;
   const float* y_scale;
-  /* LayerNorm folded into the GEMMs around it (bf16 activations and weights, fp32 residual stream; model.py:51,59's
-   * norm1 / norm2 without a kernel of their own):
-   *   PRODUCER - a RESID launch on the fp32 stream with y_bf16_copy != NULL also writes bf16(y) to y_bf16_copy (row
-   *     stride y_copy_ld elements) and, per row and 64-column block, (mean, sum (y - mean)^2) as two floats at
-   *     y_rowstat_partials[(m * N/64 + block) * 2]; N % 64 == 0.  rajni_ln_stats() turns them into (mean, rstd) per row.
-   *   CONSUMER - a BIAS / GELU launch with x_rowstats != NULL (fp32 [M][2] = mean, rstd of row m of the STREAM; `x` is the
-   *     producer's bf16 copy) and w_colsum (fp32 [N] = sum_k w[n][k]) computes
-   *         y = epi( rstd[m] * (x w^T - mean[m] * w_colsum[n]) + bias[n] )
-   *     which equals epi( LN(stream) W^T + b ) when w = bf16(W * gamma) and bias = b + W beta (the caller folds them). */
-  const float* x_rowstats;
-  const float* w_colsum;
-  void* y_bf16_copy; long y_copy_ld;
-  float* y_rowstat_partials;
 } rajni_linear_args;
 int rajni_linear(const rajni_linear_args* args, rajni_stream_t stream);
 
@@ -190,10 +169,6 @@ typedef struct {
   /* act_fp8 plans only: max_n ||W1deq[n,:]||_2 and max_n |b1[n]| of this block's fc1 (the hidden-activation
    * bound of rajni_layernorm_fp8) */
   float fc1_rownorm_max, fc1_bias_absmax;
-  /* ln_fold plans only: gamma-folded copies bf16(W * gamma) of the qkv / fc1 weights with b + W beta and the column
-   * sums of the folded weight (see rajni_linear_args.x_rowstats); NULL = this site keeps its LayerNorm kernel */
-  const void* qkv_wf; const float* qkv_bf; const float* qkv_cs;
-  const void* fc1_wf; const float* fc1_bf; const float* fc1_cs;
 } rajni_block;
 
 typedef struct {
@@ -224,12 +199,6 @@ typedef struct {
                                                   (rajni_layernorm_fp8, rajni_linear_args.x_scale).  Attention, proj,
                                                   patch embed, head and the residual stream are unchanged.
                                                   C % 256 == 0 and hidden % 256 == 0.  0 (default): bf16 activations */
-  int ln_fold;                                 /* 1: norm1 / norm2 of every block whose rajni_block carries folded
-                                                  weights run as epilogue extras of the GEMMs around them instead of a
-                                                  kernel (bf16 model, fp32 residual stream, bf16 weights, C % 64 == 0);
-                                                  block 0's norm1 (its input comes from the patch embed) and the final
-                                                  norm stay kernels */
-  int32_t* ln_guard;                           /* device int32 or NULL: max over the forward of floor(|mean| * rstd) */
 } rajni_vit_plan;
 
 size_t rajni_vit_workspace_bytes(const rajni_vit_plan* plan);

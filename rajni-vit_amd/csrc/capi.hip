@@ -145,11 +145,6 @@ int rajni_layernorm(const void* x, long x_row_stride, const float* w, const floa
   return launch_layernorm(x, x_row_stride, w, b, y, rows, C, eps, x_f32, dtype, (hipStream_t)stream);
 }
 
-int rajni_ln_stats(const float* partials, float* stats, int rows, int nblocks, float eps, int32_t* guard,
-                   rajni_stream_t stream) {
-  return launch_ln_stats(partials, stats, rows, nblocks, eps, guard, (hipStream_t)stream);
-}
-
 int rajni_layernorm_fp8(const void* x, long x_row_stride, const float* w, const float* b, void* y_q,
                         float* y_scale, float* hid_scale, float w1_rownorm_max, float b1_absmax,
                         int rows, int C, float eps, int x_f32, rajni_stream_t stream) {

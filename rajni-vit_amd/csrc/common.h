@@ -127,7 +127,6 @@ int launch_patch_embed(const void* images, const void* w, const float* bias, con
 size_t patch_embed_workspace_bytes(int B, int Cin, int S, int P, int dtype);   // 0: im2col fused into the GEMM loads
 int launch_layernorm(const void* x, long xs, const float* w, const float* b, void* y, int rows,
                      int C, float eps, int x_f32, int dtype, hipStream_t s);
-int launch_ln_stats(const float* partials, float* stats, int rows, int nblocks, float eps, int32_t* guard, hipStream_t s);
 int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b, void* yq, float* yscale,
                          float* hscale, float wnorm, float bmax, int rows, int C, float eps, int x_f32, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,

@@ -18,7 +18,6 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Workspace {
   char *xa, *xb, *xn, *qkv, *att, *hid, *clsn, *scf, *cols;
   float *xs, *hs;          // act_fp8 plans: per-row scales of the e4m3 LayerNorm output / MLP hidden activations
-  float *lnp, *lns;        // ln_fold plans: per-row (mean, M2) partials of 64-column blocks, per-row (mean, rstd)
   size_t total, cols_bytes;
 };
 
@@ -35,13 +34,10 @@ Workspace carve(const rajni_vit_plan& p) {
   w.cols_bytes = patch_embed_workspace_bytes(p.B, p.in_chans, p.img_size, p.patch_size, p.dtype);   // 0 when fused
   const size_t ocols = take(w.cols_bytes);
   const size_t oxs = take(p.act_fp8 ? rows * sizeof(float) : 0), ohs = take(p.act_fp8 ? rows * sizeof(float) : 0);
-  const bool fold = p.ln_fold && p.C % 64 == 0;
-  const size_t olnp = take(fold ? rows * (p.C / 64) * 2 * sizeof(float) : 0), olns = take(fold ? rows * 2 * sizeof(float) : 0);
   char* base = (char*)p.workspace;
   w.xa = base + oxa; w.xb = base + oxb; w.xn = base + oxn; w.qkv = base + oqkv; w.att = base + oatt;
   w.hid = base + ohid; w.clsn = base + ocls; w.scf = base + oscf; w.cols = base + ocols;
   w.xs = reinterpret_cast<float*>(base + oxs); w.hs = reinterpret_cast<float*>(base + ohs);
-  w.lnp = reinterpret_cast<float*>(base + olnp); w.lns = reinterpret_cast<float*>(base + olns);
   w.total = off;
   return w;
 }
@@ -64,9 +60,6 @@ int check_plan(const rajni_vit_plan& p) {
                 "rajni_vit_forward: C and hidden must be multiples of 64");
   RAJNI_REQUIRE(p.patch_w && p.cls_token && p.pos_embed && p.norm_w && p.norm_b && p.head_w,
                 RAJNI_ERR_INVALID, "rajni_vit_forward: null weight pointer");
-  if (p.ln_fold)
-    RAJNI_REQUIRE(p.dtype == RAJNI_BF16 && !p.resid_bf16 && !p.act_fp8 && p.C % 64 == 0, RAJNI_ERR_UNSUPPORTED,
-                  "rajni_vit_forward: ln_fold needs a bf16 model with the fp32 residual stream, bf16 activations, C %% 64 == 0");
   if (p.act_fp8) {
     RAJNI_REQUIRE(p.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_vit_forward: act_fp8 needs a bf16 model");
     RAJNI_REQUIRE(p.C % 256 == 0 && p.hidden % 256 == 0 && p.C >= 512, RAJNI_ERR_UNSUPPORTED,
@@ -110,30 +103,19 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
   char* cur = w.xa;
   char* oth = w.xb;
   const void* carried = nullptr;  // scores of the tokens currently in `cur` (model.py:39,53,63)
-  // LN fold: true when the residual epilogue that produced `cur` also wrote its bf16 copy (into w.xn) and the row
-  // statistics (w.lns) - the next LayerNorm site then is an epilogue extra of its consumer GEMM, not a kernel
-  bool folded_in = false;
-  // make a residual launch the producer of the next LayerNorm site
-  auto produce = [&](rajni_linear_args& g) { g.y_bf16_copy = w.xn; g.y_copy_ld = C; g.y_rowstat_partials = w.lnp; };
-  auto finish_stats = [&](int rows_) { return launch_ln_stats(w.lnp, w.lns, rows_, C / 64, p.ln_eps, p.ln_guard, s); };
-  const bool last_is_cls_only = p.cls_only_last_block && p.blocks[p.depth - 1].keep == 0;
 
   for (int i = 0; i < p.depth; ++i) {
     const rajni_block& blk = p.blocks[i];
     if (p.token_counts) p.token_counts[i] = N;  // model.py:43
     const int M = B * N;
     // ---- norm1 + qkv on ALL N tokens (model.py:51, attention.py:21-22)
-    const bool fold_qkv = folded_in && blk.qkv_wf != nullptr;
-    if (fold_qkv) rc = RAJNI_OK;   // norm1 = epilogue extras of the previous fc2 (copy + statistics) and of this qkv
-    else if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm1_w, blk.norm1_b, w.xn, w.xs, nullptr, 0.f, 0.f, M, C, p.ln_eps, sf32, s);
+    if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm1_w, blk.norm1_b, w.xn, w.xs, nullptr, 0.f, 0.f, M, C, p.ln_eps, sf32, s);
     else rc = launch_layernorm(cur, C, blk.norm1_w, blk.norm1_b, w.xn, M, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
     rajni_linear_args g{};
     g.dtype = dt;
     g.x = w.xn; g.lda = C; g.w = blk.qkv_w; g.ldw = C; g.bias = blk.qkv_b; g.w_scale = blk.qkv_s;
     if (p.act_fp8) g.x_scale = w.xs;
-    if (fold_qkv) { g.w = blk.qkv_wf; g.bias = blk.qkv_bf; g.w_colsum = blk.qkv_cs; g.x_rowstats = w.lns; }
-    folded_in = false;
     g.y = w.qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epilogue = RAJNI_EPI_BIAS;
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
@@ -223,8 +205,6 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     g.dtype = dt;
     g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1; g.w_scale = blk.proj_s;
     g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
-    const bool fold_fc1 = p.ln_fold && blk.fc1_wf != nullptr;
-    if (fold_fc1) produce(g);
     if (idx) {
       g.r_idx = idx; g.r_np = Np; g.r_nsrc = N;
       g.y = oth; g.ldc = C;
@@ -238,8 +218,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     N = Np;
 
     // ---- MLP (model.py:59): norm2 -> fc1 + GELU -> fc2 + LayerScale + residual (in place)
-    if (fold_fc1) rc = finish_stats(Mp);
-    else if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm2_w, blk.norm2_b, w.xn, w.xs, w.hs, blk.fc1_rownorm_max,
+    if (p.act_fp8) rc = launch_layernorm_fp8(cur, C, blk.norm2_w, blk.norm2_b, w.xn, w.xs, w.hs, blk.fc1_rownorm_max,
                                                   blk.fc1_bias_absmax, Mp, C, p.ln_eps, sf32, s);
     else rc = launch_layernorm(cur, C, blk.norm2_w, blk.norm2_b, w.xn, Mp, C, p.ln_eps, sf32, dt, s);
     if (rc != RAJNI_OK) return rc;
@@ -248,7 +227,6 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     g.x = w.xn; g.lda = C; g.w = blk.fc1_w; g.ldw = C; g.bias = blk.fc1_b; g.w_scale = blk.fc1_s;
     g.y = w.hid; g.ldc = p.hidden; g.M = Mp; g.N = p.hidden; g.K = C; g.epilogue = RAJNI_EPI_BIAS_GELU;
     if (p.act_fp8) { g.x_scale = w.xs; g.y_scale = w.hs; }   // e4m3 in, e4m3 out (per-row scales)
-    if (fold_fc1) { g.w = blk.fc1_wf; g.bias = blk.fc1_bf; g.w_colsum = blk.fc1_cs; g.x_rowstats = w.lns; }
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
     g = rajni_linear_args{};
@@ -257,17 +235,8 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (p.act_fp8) g.x_scale = w.hs;
     g.resid = cur; g.ldr = C; g.y = cur; g.ldc = C; g.M = Mp; g.N = C; g.K = p.hidden;
     g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
-    // the next block's norm1 folds into this epilogue and its qkv - unless that block is the CLS-only last block
-    const bool fold_next = p.ln_fold && i + 1 < p.depth && p.blocks[i + 1].qkv_wf != nullptr &&
-                           !(last_is_cls_only && i + 1 == p.depth - 1);
-    if (fold_next) produce(g);
     rc = launch_linear(g, s);
     if (rc != RAJNI_OK) return rc;
-    if (fold_next) {
-      rc = finish_stats(Mp);
-      if (rc != RAJNI_OK) return rc;
-      folded_in = true;
-    }
   }
 
   // ---- final norm on the CLS rows only (LN is per token; model.py:65-66) + head

@@ -40,11 +40,6 @@ struct GemmParams {
   const float* wscale;          // W8 kernels: W is fp8 e4m3 [N,K] and wscale[n] its per-row dequantisation scale
   const float* xscale;          // fp8 x fp8 kernel: X is fp8 e4m3 [M,K] and xscale[m] its per-row dequantisation scale
   const float* yscale;          // ... EPI_GELU8: output row m is stored as e4m3(gelu(.) / yscale[m])
-  // LayerNorm folded into the GEMMs around it (template flag LNF, see "LN fold" below)
-  const float2* rowstats;       // consumer (BIAS / GELU): (mean, rstd) of input row m;  X is the bf16 copy of the stream
-  const float* colsum;          // consumer: sum_k W'[n][k] of the gamma-folded weight
-  void* xcopy; long ldx;        // producer (RESID, fp32 stream): bf16 copy of the output rows
-  float2* partials; int ncb;    // producer: (mean, M2) of output row m over column block cb (64 columns) at [m * ncb + cb]
   const float* bias;
   const float* gamma;
   const void* R; long ldr;      // residual stream rows (bf16 or fp32, see SF32)
@@ -265,44 +260,8 @@ template <> struct WFragT<true> { typedef fp8x8_raw type; };
 __device__ __forceinline__ bf16x8 w_frag_bf16(const bf16x8& f) { return f; }
 __device__ __forceinline__ bf16x8 w_frag_bf16(const fp8x8_raw& f) { return fp8x8_to_bf16(__builtin_bit_cast(uint2, f)); }
 
-// ---- LN fold ------------------------------------------------------------------------------------------------
-// LayerNorm between a residual-epilogue GEMM (proj / fc2) and the linear that consumes it (fc1 / the next qkv) as
-// two epilogue extras instead of a kernel that reads the fp32 stream and writes a bf16 tensor:
-//   producer (EPI_RESID on the fp32 stream, LNF): besides the fp32 row it writes a bf16 COPY of it - the consumer's X
-//     operand - and, per 64-column block of the row, (mean, M2 = sum (x - mean)^2) from the fp32 values; a 12-element
-//     Chan combination per row (ln_stats_kernel) turns the blocks into (mean, rstd) - no cancellation at any |mean|;
-//   consumer (EPI_BIAS / EPI_GELU, LNF):  LN(x) W^T + b  =  rstd * (xb W'^T - mean * colsum(W')) + b'
-//     with W' = bf16(W * gamma), b' = b + W beta (host, once per weight), xb = bf16(x).
-// What changes numerically: the MFMA sees bf16(x) instead of bf16(LN(x)) - the same relative rounding per element,
-// amplified by sqrt(1 + (mean/std)^2) of the token (the guard ln_stats_kernel raises) - and W' instead of W (one more
-// bf16 rounding of the weights).
-__device__ __forceinline__ float xor_sum16_32(float v) {   // sum over the 4 lanes l15 + 16 g that share an output row
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-// one output row of the producer: o[4 * ni + e] = column n0w + 16 ni + 4 g + e (natural order), all 64 columns valid
-__device__ __forceinline__ void ln_fold_row(const GemmParams& p, long orow, int n0w, int g, const float* o) {
-  bf16_t* xc = reinterpret_cast<bf16_t*>(p.xcopy) + orow * p.ldx + n0w + 4 * g;
-  float s = 0.f;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    *reinterpret_cast<uint2*>(xc + 16 * ni) = make_uint2(pack2bf(o[4 * ni], o[4 * ni + 1]), pack2bf(o[4 * ni + 2], o[4 * ni + 3]));
-    s += (o[4 * ni] + o[4 * ni + 1]) + (o[4 * ni + 2] + o[4 * ni + 3]);
-  }
-  const float mean = xor_sum16_32(s) * (1.0f / 64.0f);
-  float d = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float t = o[j] - mean;
-    d = fmaf(t, t, d);
-  }
-  d = xor_sum16_32(d);
-  if (g == 0) p.partials[orow * p.ncb + (n0w >> 6)] = make_float2(mean, d);
-}
-
 // natural-order epilogue of one output row (fp32 stream): v = accumulators + bias on entry
-template <int EPI, bool LNF = false>
+template <int EPI>
 __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int n0w, int g, float* v, const float* gam) {
   long orow = m, rrow = m;
   int pp = 0;
@@ -344,11 +303,6 @@ __device__ __forceinline__ void epilogue_row_nat(const GemmParams& p, int m, int
         }
     }
   }
-  if constexpr (LNF && EPI == EPI_RESID) {
-    // host: N % 64 == 0, so a wave's 64-column block lies wholly inside the output or wholly past it (N = 192 on 128-wide
-    // tiles: the second tile's upper half; found by tools/fuzz_linear_r2.py - it wrote into the next row's copy)
-    if (n0w < p.N) ln_fold_row(p, orow, n0w, g, v);
-  }
 }
 
 // Residual rows of a tile, loaded EARLY (during the last K step) for the fp32-stream RESID epilogue:
@@ -385,57 +339,17 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 }
 
 // shared tail of every bf16 tiling: bias/gamma for this lane's columns, then one row per m-tile
-template <int EPI, bool SF32, int MI, bool W8 = false, bool LNF = false>
+template <int EPI, bool SF32, int MI, bool W8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n0w,
                                               int l15, int g, ResidPrefetch<MI>& pre, int m_lo = 0,
                                               bool interior = false) {
-  static_assert(!LNF || ((EPI == EPI_BIAS || EPI == EPI_GELU || (EPI == EPI_RESID && SF32)) && !W8),
-                "LN fold: consumer = bias / GELU, producer = residual epilogue on the fp32 stream; bf16 weights");
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
   if constexpr (MAP == MAP_SEC && (EPI == EPI_BIAS || EPI == EPI_GELU)) {
     // interior tile of a bf16-output launch (QKV, FC1 - the bulk of all tiles): no row or column guard, the
     // lane's 2 x 8 columns of bias (and fp8 scale) as four 16-byte loads, two 16-byte stores per row.  The
     // guarded general path below costs ~3x the instructions in exec-mask branches alone.
-    if constexpr (LNF) {
-      // LN-fold consumer, interior tile: y = rstd[m] * (acc - mean[m] * colsum[n]) + b'[n].  The lane's 2 x 8 columns
-      // are done one half at a time (8 + 8 column constants live instead of 32: the 256 x 256 tiling has ~12 VGPRs
-      // to spare) and a row's (mean, rstd) is fetched one row ahead.
-      if (interior) {
-        bf16_t* Y = reinterpret_cast<bf16_t*>(p.Y);
-#pragma unroll
-        for (int hc = 0; hc < 2; ++hc) {
-          const int c0 = n0w + 8 * g + 32 * hc;
-          float bs[8], cs[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bs[j] = 0.f;
-          if (p.bias != nullptr) load8<float>(p.bias + c0, bs);
-          load8<float>(p.colsum + c0, cs);
-          float2 st_next = p.rowstats[m_base + l15];
-          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the note in the general path
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const float2 st = st_next;
-            if (mi + 1 < MI) st_next = p.rowstats[m_base + (mi + 1) * 16 + l15];
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {   // v[j]: column c0 + j = accumulator (ni = 2 hc + (j >> 2), rg = j & 3)
-              const int ni = 2 * hc + (j >> 2), rg = j & 3;
-              v[j] = fmaf(st.y, fmaf(-st.x, cs[j], acc[ni][mi][rg]), bs[j]);
-            }
-            if (EPI == EPI_GELU) {
-#pragma unroll
-              for (int j = 0; j < 8; j += 2) {
-                const f32x2 y = gelu_pk(f32x2{v[j], v[j + 1]});
-                v[j] = y[0]; v[j + 1] = y[1];
-              }
-            }
-            *reinterpret_cast<uint4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + c0) = pack8(v);
-          }
-        }
-        return;
-      }
-    } else if (interior) {
+    if (interior) {
       const int ca = n0w + 8 * g, cb = ca + 32;
       float bs[16], ws[16];
 #pragma unroll
@@ -487,10 +401,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
       wsc[j] = n < p.N ? p.wscale[n] : 0.f;
     }
   }
-  constexpr bool LNC = LNF && (EPI == EPI_BIAS || EPI == EPI_GELU);   // LN-fold consumer / producer
-  constexpr bool LNP = LNF && EPI == EPI_RESID;
-  // (LN-fold consumers, edge tiles only: column sums and row statistics are loaded where they are used - held in
-  //  registers across this path they cost the 256 x 256 GELU instantiation 20 bytes of spills)
   // Every vector-memory LOAD issued so far (these, and the residual rows prefetched in the last K step) has
   // landed after this explicit wait, on EVERY path - including the ones that skip all uses (a row tile
   // past M).  Without it hipcc's waitcnt pass carries "register X may still be the target of a load" back
@@ -509,7 +419,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
       float* Y = reinterpret_cast<float*>(p.Y);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        float ov[LNP ? 16 : 1];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float4 o;
@@ -518,9 +427,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           o.z = fmaf(gam[4 * ni + 2], acc[ni][mi][2] + bias[4 * ni + 2], pre.r[mi][ni].z);
           o.w = fmaf(gam[4 * ni + 3], acc[ni][mi][3] + bias[4 * ni + 3], pre.r[mi][ni].w);
           *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g) = o;
-          if constexpr (LNP) { ov[4 * ni] = o.x; ov[4 * ni + 1] = o.y; ov[4 * ni + 2] = o.z; ov[4 * ni + 3] = o.w; }
         }
-        if constexpr (LNP) ln_fold_row(p, m_base + mi * 16 + l15, n0w, g, ov);
       }
       return;
     }
@@ -530,21 +437,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
     const int m = m_base + mi * 16 + l15;
     if (m >= p.M || m < m_lo) continue;
     float v[16];
-    float2 stat = make_float2(0.f, 1.f);
-    if constexpr (LNC) stat = p.rowstats[m];     // (edge tiles only: the row's statistics just in time)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        if constexpr (LNC) {
-          const int n = out_col<MAP>(n0w, g, ni * 4 + rg);
-          const float cs = n < p.N ? p.colsum[n] : 0.f;
-          v[ni * 4 + rg] = fmaf(stat.y, fmaf(-stat.x, cs, acc[ni][mi][rg]), bias[ni * 4 + rg]);
-        } else {
-          v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
-        }
-      }
-    if (NAT) epilogue_row_nat<EPI, LNP>(p, m, n0w, g, v, gam);
+      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+    if (NAT) epilogue_row_nat<EPI>(p, m, n0w, g, v, gam);
     else epilogue_row<EPI, SF32>(p, m, n0w + 8 * g, n0w + 32 + 8 * g, v, gam);
   }
 }
@@ -645,7 +542,7 @@ template <int N> __device__ __forceinline__ void wait_step() {   // lgkmcnt(0) +
 // Eight waves of (MI*16) x 64 outputs each.
 // TAG does nothing in the body: residual launches with K <= N (the attention projection, bound by its fp32-stream
 // epilogue) run an instantiation of their own so that profilers list them apart from fc2, like bench.py's classes.
-template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int TAG = 0, bool LNF = false>
+template <int EPI, int ALOAD, bool SF32, int WM, int WN, int MI, int NS, bool W8 = false, int TAG = 0>
 __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const GemmParams p) {
   using C = Cfg<WN, NS, W8, WM * WN>;
   constexpr int NI = 4;                        // 16-column n-tiles per wave
@@ -801,14 +698,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
     if constexpr (READ) sched_half<0, MI, DMA, C::PIECES, NI>();
   };
   using T = std::true_type; using F = std::false_type;
-  // LN-fold consumers carry 16 + 2 MI more epilogue operands (column sums, row statistics): with the next tile's
-  // first fragments live through the epilogue that spills in the 256 x 256 tiling (72-112 bytes, some of it inside the
-  // K loop).  Those instantiations read no fragments in a tile's LAST half step and fetch them after the epilogue
-  // instead (one exposed LDS round trip per tile) - the fp8 kernels' arrangement (gemm_f8.h).
-  // Measured and NOT kept for the LN-fold consumers of this kernel: the peeled step makes hipcc spill six DMA pointers
-  // inside the K loop (48-64 bytes); their epilogue instead works through its columns in two halves (epilogue_tile).
-  constexpr bool LATE_FRAGS = false;
-
   const int nk = p.K / BK;        // >= NS + 1 (host checked)
   int v = blockIdx.x;
   int tile = xcd_tile_of(v, p.total_tiles);
@@ -862,11 +751,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
 #pragma unroll
       for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one K step; LAST (compile time, LATE_FRAGS instantiations only) = a tile's final step, whose second half reads no
-    // fragments.  (A run-time branch between the two forms of the half step merges their register states: 624 bytes
-    // of spills - the final step is peeled instead.)
-    auto kstep = [&](auto last_c, int kt) {
-      constexpr bool LAST = decltype(last_c)::value;
+    auto kstep = [&](int kt) {   // one K step
       // the DMA of step kt loads K-tile kt+NS; from kt = nk-NS on that is the NEXT tile's K-tile
       // 0.. (when there is no next tile the pointers stay put: harmless re-loads nobody reads)
       if (kt == nk - NS && more) advance(tile, xcd_tile_of(vn, p.total_tiles));
@@ -879,22 +764,17 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
       else wait_step<WBASE>();
       __builtin_amdgcn_s_barrier();   // ... and everyone else's: stage st is free, stage st1 readable
       asm volatile("" ::: "memory");
-      half(T{}, std::integral_constant<bool, !LAST>{}, xb, wb, xa, wa, st1, 0, dkt, st);
+      half(T{}, T{}, xb, wb, xa, wa, st1, 0, dkt, st);
       st = st1;
     };
-    if constexpr (LATE_FRAGS) {
-      for (int kt = 0; kt < nk - 1; ++kt) kstep(F{}, kt);
-      kstep(T{}, nk - 1);
-    } else {
-      for (int kt = 0; kt < nk; ++kt) kstep(F{}, kt);
-    }
+    for (int kt = 0; kt < nk; ++kt) kstep(kt);
 #ifdef RAJNI_GEMM_STAMPS
     asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][MI - 1][3]));
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI, W8, LNF>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -904,15 +784,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
       }
     }
 #endif
-    if constexpr (LATE_FRAGS) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {   // the next tile's (K-tile 0, ks 0) fragments: landed and barrier-passed during the last K step
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wa[i] = *reinterpret_cast<const WFrag*>(smem + st * C::STAGE_BYTES + wo[0] + w_ni_off(i));
-#pragma unroll
-        for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(smem + st * C::STAGE_BYTES + xo[0] + i * 2048);
-      }
-    }
     prev_full = inter;
     if (!more) break;
     v = vn;
@@ -934,7 +805,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // double buffered: 64 KiB
 __device__ __forceinline__ int key_x(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_w(int row) { return ((row >> 4) & 3) * 2 + ((row >> 1) & 1); }
 
-template <int EPI, int ALOAD, bool SF32, bool W8 = false, bool LNF = false>
+template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams p) {
   constexpr int MAP = col_map(EPI, SF32);      // W-row permutation = which output columns a lane owns
   constexpr int PW = W8 ? 2 : 4;               // W pieces per wave per K step (fp8 tile is 8 KiB)
@@ -1027,7 +898,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_tn_128x128(const GemmParams 
     }
   }
 
-  epilogue_tile<EPI, SF32, 4, W8, LNF>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g, pre);
+  epilogue_tile<EPI, SF32, 4, W8>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g, pre);
 }
 }  // namespace small
 
@@ -1276,7 +1147,7 @@ inline int stream_grid(int total_tiles, int cus) { return total_tiles <= cus ? t
 // are best: 9.09 -> 9.03 ms (+0.5-0.8 %), 4 units neutral, 6 units -1.2 %.  rajni_debug_set_resid_stagger(0) turns it off.
 int g_resid_stagger = 2;
 
-template <int EPI, int ALOAD, bool SF32, bool W8 = false, bool LNF = false>
+template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   p.stamps = rajni_g_stamps;
   p.stagger = g_resid_stagger;
@@ -1307,38 +1178,38 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0, LNF>, C::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>, C::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, LNF>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2, cus);   // fp8 W: same blocks as bf16 (measured)
     const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1, LNF>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     } else {
-      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0, LNF>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     }
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0, LNF>, C::LDS_BYTES, attr[2])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>, C::LDS_BYTES, attr[2])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, LNF>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2, cus);
     const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1, LNF>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     } else {
-      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0, LNF>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
     }
   } else {
     constexpr int lds = small::LDS_BYTES;
-    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8, LNF>, lds, attr[0])) != RAJNI_OK) return rc;
+    if ((rc = set_lds_attr(&small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>, lds, attr[0])) != RAJNI_OK) return rc;
     p.total_tiles = t128;
-    hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8, LNF>), dim3(t128), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((small::gemm_bf16_tn_128x128<EPI, ALOAD, SF32, W8>), dim3(t128), dim3(256), lds, s, p);
   }
   RAJNI_CHECK_LAUNCH("gemm_bf16_tn");
   return RAJNI_OK;
@@ -1449,8 +1320,6 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
     }
   }
   RAJNI_REQUIRE(a.y_scale == nullptr, RAJNI_ERR_INVALID, "rajni_linear: y_scale without x_scale");
-  RAJNI_REQUIRE((a.x_rowstats == nullptr && a.y_bf16_copy == nullptr) || (a.w_scale == nullptr && a.dtype == RAJNI_BF16),
-                RAJNI_ERR_UNSUPPORTED, "rajni_linear: the LayerNorm fold exists for bf16 weights and activations only");
   if (a.w_scale != nullptr) {   // fp8 e4m3 weights, bf16 activations
     RAJNI_REQUIRE(a.dtype == RAJNI_BF16, RAJNI_ERR_UNSUPPORTED, "rajni_linear: fp8 weights need bf16 activations");
     RAJNI_REQUIRE(a.ldw % 16 == 0, RAJNI_ERR_INVALID, "rajni_linear: fp8 weights need ldw %% 16 == 0");
@@ -1478,23 +1347,6 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
         rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
         return RAJNI_ERR_INVALID;
     }
-  }
-  // LN fold (rajni_linear_args.x_rowstats / w_colsum on the consumer side, y_bf16_copy / y_rowstat_partials on the
-  // producer side): bf16 models with the fp32 residual stream only
-  const bool ln_consumer = a.x_rowstats != nullptr, ln_producer = a.y_bf16_copy != nullptr;
-  if (ln_consumer) {
-    RAJNI_REQUIRE(a.w_colsum != nullptr && a.epilogue != RAJNI_EPI_BIAS_RESID, RAJNI_ERR_INVALID,
-                  "rajni_linear: x_rowstats needs w_colsum and a bias / GELU epilogue");
-    p.rowstats = reinterpret_cast<const float2*>(a.x_rowstats); p.colsum = a.w_colsum;
-    return a.epilogue == RAJNI_EPI_BIAS ? launch_gemm<EPI_BIAS, ALOAD_PLAIN, false, false, true>(p, KC_GEMM_BIAS, s)
-                                        : launch_gemm<EPI_GELU, ALOAD_PLAIN, false, false, true>(p, KC_GEMM_GELU, s);
-  }
-  if (ln_producer) {
-    RAJNI_REQUIRE(a.epilogue == RAJNI_EPI_BIAS_RESID && a.stream_f32 && a.resid != nullptr && a.ldr % 8 == 0 &&
-                  a.y_rowstat_partials != nullptr && a.N % 64 == 0 && a.y_copy_ld % 8 == 0 && (uintptr_t)a.y_bf16_copy % 16 == 0,
-                  RAJNI_ERR_INVALID, "rajni_linear: y_bf16_copy needs the fp32-stream RESID epilogue, y_rowstat_partials, N %% 64 == 0");
-    p.xcopy = a.y_bf16_copy; p.ldx = a.y_copy_ld; p.partials = reinterpret_cast<float2*>(a.y_rowstat_partials); p.ncb = a.N / 64;
-    return launch_gemm<EPI_RESID, ALOAD_PLAIN, true, false, true>(p, a.K <= a.N ? KC_GEMM_RESID_SQ : KC_GEMM_RESID, s);
   }
   switch (a.epilogue) {
     case RAJNI_EPI_BIAS: return launch_gemm<EPI_BIAS, ALOAD_PLAIN, false>(p, KC_GEMM_BIAS, s);

@@ -156,28 +156,6 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   }
 }
 
-// LN fold, middle step (see "LN fold" in gemm.hip): (mean, M2) of each 64-column block of a row -> (mean, rstd) of
-// the row by Chan's combination (equal block sizes: mean = average of the block means, M2 = sum M2_b + 64 sum
-// (mean_b - mean)^2), one thread per row, fixed order.  guard: atomicMax of floor(|mean| * rstd).
-__global__ void __launch_bounds__(256) ln_stats_kernel(const float2* __restrict__ part, float2* __restrict__ stats,
-                                                       int rows, int nb, float eps, int* __restrict__ guard) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  const float2* pr = part + (long)row * nb;
-  float msum = 0.f, m2 = 0.f;
-  for (int b = 0; b < nb; ++b) { const float2 v = pr[b]; msum += v.x; m2 += v.y; }
-  const float mean = msum / (float)nb;
-  float between = 0.f;
-  for (int b = 0; b < nb; ++b) { const float d = pr[b].x - mean; between = fmaf(d, d, between); }
-  const float var = fmaf(64.0f, between, m2) / (64.0f * (float)nb);
-  const float rstd = rsqrtf(var + eps);
-  stats[row] = make_float2(mean, rstd);
-  if (guard != nullptr) {
-    const float z = fminf(fabsf(mean) * rstd, 1.0e6f);
-    if (z >= 1.0f) atomicMax(guard, (int)z);
-  }
-}
-
 // dst[b, j, :] = src[b, idx[b, j], :]   rows of `row_chunks` 16-byte chunks; one wave per row
 __global__ void __launch_bounds__(256) gather_rows_kernel(const uint4* __restrict__ src,
                                                          const int* __restrict__ idx,
@@ -229,15 +207,6 @@ int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b,
     hipLaunchKernelGGL((layernorm_fp8_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (unsigned char*)yq,
                        yscale, hscale, wnorm, bmax, rows, C, eps);
   RAJNI_CHECK_LAUNCH("layernorm_fp8_kernel");
-  return RAJNI_OK;
-}
-
-int launch_ln_stats(const float* partials, float* stats, int rows, int nblocks, float eps, int32_t* guard, hipStream_t s) {
-  RAJNI_REQUIRE(partials && stats && rows > 0 && nblocks > 0, RAJNI_ERR_INVALID, "rajni_ln_stats: bad arguments");
-  ProfScope prof(KC_LAYERNORM, s, 0.0, (8.0 * nblocks + 8.0) * rows);
-  hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2*>(partials),
-                     reinterpret_cast<float2*>(stats), rows, nblocks, eps, reinterpret_cast<int*>(guard));
-  RAJNI_CHECK_LAUNCH("ln_stats_kernel");
   return RAJNI_OK;
 }
 

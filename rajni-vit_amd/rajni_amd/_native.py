@@ -31,9 +31,7 @@ class LinearArgs(C.Structure):
                 ("r_idx", c_void_p), ("r_np", c_int), ("r_nsrc", c_int),
                 ("y", c_void_p), ("ldc", c_long), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("epilogue", c_int), ("dtype", c_int), ("stream_f32", c_int), ("w_scale", c_void_p),
-                ("x_scale", c_void_p), ("y_scale", c_void_p),
-                ("x_rowstats", c_void_p), ("w_colsum", c_void_p), ("y_bf16_copy", c_void_p), ("y_copy_ld", c_long),
-                ("y_rowstat_partials", c_void_p)]
+                ("x_scale", c_void_p), ("y_scale", c_void_p)]
 
 
 class Block(C.Structure):
@@ -47,9 +45,7 @@ class Block(C.Structure):
                 ("keep_idx", c_void_p), ("scores", c_void_p), ("next_scores", c_void_p),
                 ("forced_keep_idx", c_void_p),
                 ("qkv_s", c_void_p), ("proj_s", c_void_p), ("fc1_s", c_void_p), ("fc2_s", c_void_p),
-                ("fc1_rownorm_max", c_float), ("fc1_bias_absmax", c_float),
-                ("qkv_wf", c_void_p), ("qkv_bf", c_void_p), ("qkv_cs", c_void_p),
-                ("fc1_wf", c_void_p), ("fc1_bf", c_void_p), ("fc1_cs", c_void_p)]
+                ("fc1_rownorm_max", c_float), ("fc1_bias_absmax", c_float)]
 
 
 class VitPlan(C.Structure):
@@ -62,7 +58,7 @@ class VitPlan(C.Structure):
                 ("norm_w", c_void_p), ("norm_b", c_void_p), ("head_w", c_void_p), ("head_b", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("token_counts", C.POINTER(C.c_int32)), ("logits_ld", c_int), ("cls_only_last_block", c_int),
-                ("resid_bf16", c_int), ("act_fp8", c_int), ("ln_fold", c_int), ("ln_guard", c_void_p)]
+                ("resid_bf16", c_int), ("act_fp8", c_int)]
 
 
 _SIGS = {
@@ -78,7 +74,6 @@ _SIGS = {
                                 c_int, c_void_p]),
     "rajni_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                 c_int, c_int, c_void_p]),
-    "rajni_ln_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "rajni_layernorm_fp8": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                     c_int, c_int, c_float, c_int, c_void_p]),
     "rajni_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
@@ -102,7 +97,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
-ABI_VERSION = 6     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
+ABI_VERSION = 7     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
 _lib: Optional[C.CDLL] = None
 
 

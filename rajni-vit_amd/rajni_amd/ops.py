@@ -200,9 +200,7 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
            epilogue: int = nat.EPI_BIAS, gamma: Optional[torch.Tensor] = None,
            resid: Optional[torch.Tensor] = None, r_idx: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None,
-           x_scale: Optional[torch.Tensor] = None, y_scale: Optional[torch.Tensor] = None,
-           x_rowstats: Optional[torch.Tensor] = None, w_colsum: Optional[torch.Tensor] = None,
-           y_bf16_copy: Optional[torch.Tensor] = None, y_rowstat_partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+           x_scale: Optional[torch.Tensor] = None, y_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epi(x @ W^T): x [..., K]; w_packed from pack_weight(); bias/gamma fp32 [n_out].
     With `w_scale` (fp32 [n_out]) w_packed is the uint8 e4m3 tensor of pack_weight_fp8() and x is bf16.
     resid [B, N_src, n_out] (+ r_idx [B, Np] int32 to gather its rows) for EPI_BIAS_RESID; an fp32
@@ -230,12 +228,6 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, n_out: int, bias: Optional[t
     a.y, a.ldc = out.data_ptr(), out.shape[-1] if out.dim() == 2 else out.stride(-2)
     a.M, a.N, a.K, a.epilogue, a.dtype, a.stream_f32 = M, n_out, K, epilogue, nat.dtype_code(act_dtype), stream_f32
     a.x_scale, a.y_scale = nat.ptr(x_scale), nat.ptr(y_scale)
-    # LN fold (see fold_layernorm / ln_stats below): consumer side x_rowstats + w_colsum, producer side y_bf16_copy +
-    # y_rowstat_partials
-    a.x_rowstats, a.w_colsum = nat.ptr(x_rowstats), nat.ptr(w_colsum)
-    a.y_bf16_copy, a.y_rowstat_partials = nat.ptr(y_bf16_copy), nat.ptr(y_rowstat_partials)
-    if y_bf16_copy is not None:
-        a.y_copy_ld = y_bf16_copy.shape[-1]
     if resid is not None:
         resid = resid.contiguous()
         a.resid, a.ldr = resid.data_ptr(), resid.shape[-1]
@@ -267,32 +259,3 @@ def patch_embed(images: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor
                                               embed_dim, _dt(images), nat.ptr(ws), nbytes, nat.stream_ptr(images.device)),
                   "rajni_patch_embed")
     return x
-
-
-def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor,
-                   dtype=torch.bfloat16, device=None):
-    """LayerNorm folded into the Linear that consumes it (rajni_linear_args.x_rowstats):
-        LN(x) W^T + b  =  rstd * (x W'^T - mean * colsum(W')) + b',   W' = dtype(W * gamma),  b' = b + W beta
-    Returns (packed W' [ceil256(N), K] in `dtype`, b' fp32 [N], colsum(W') fp32 [N]).  All inputs are taken as the model
-    dtype holds them; colsum is taken over the ROUNDED W' - what the MFMA multiplies."""
-    w32 = weight.detach().to(dtype).to(torch.float32)
-    g32 = ln_weight.detach().to(dtype).to(torch.float32)
-    b32 = ln_bias.detach().to(dtype).to(torch.float32)
-    wf = (w32 * g32[None, :]).to(dtype)
-    bias32 = bias.detach().to(dtype).to(torch.float32) if bias is not None else torch.zeros(w32.shape[0], device=w32.device)
-    bf = bias32 + w32 @ b32
-    cs = wf.to(torch.float32).sum(dim=1)
-    dev = device if device is not None else weight.device
-    return pack_weight(wf, dtype, dev), bf.to(dev).contiguous(), cs.to(dev).contiguous()
-
-
-def ln_stats(partials: torch.Tensor, eps: float, guard: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """partials fp32 [rows, nblocks, 2] of a producer launch (linear(..., y_rowstat_partials=)) -> fp32 [rows, 2] =
-    (mean, rstd) per row; `guard` (int32 [1]) receives atomicMax of floor(|mean| * rstd)."""
-    nat.require_device(partials, "partials")
-    rows, nb = partials.shape[0], partials.shape[1]
-    stats = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
-    with nat.device_guard(partials.device):
-        nat.check(nat.lib().rajni_ln_stats(partials.data_ptr(), stats.data_ptr(), rows, nb, float(eps), nat.ptr(guard),
-                                           nat.stream_ptr(partials.device)), "rajni_ln_stats")
-    return stats

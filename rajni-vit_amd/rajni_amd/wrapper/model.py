@@ -24,9 +24,6 @@ from .. import ops
 from .attention import RAJNIAttention
 
 
-LN_FOLD_DEFAULT = False
-
-
 def normalise_schedule(schedule) -> Dict[int, Dict]:
     """{block index: {"keep_ratio": float, "update": bool}} with int keys.  A missing `keep_ratio`
     raises KeyError like the reference (model.py:18); `update` defaults to True (model.py:19)."""
@@ -81,10 +78,6 @@ class RAJNIViTWrapper(nn.Module):
         self._weight_format = "model"
         # opt-in: compute the last block for the CLS row only (the head reads nothing else, model.py:65-66)
         self._cls_only_last = False
-        # norm1 / norm2 as epilogue extras of the GEMMs around them instead of kernels (`set_ln_fold`): bf16 models
-        # with the fp32 residual stream and bf16 weights
-        self._ln_fold = LN_FOLD_DEFAULT
-        self._ln_guard = None      # device int32: max over forwards of floor(|token mean| * rstd) seen by the fold
 
     # ------------------------------------------------------------------------------------------
     def get_last_stats(self):
@@ -118,7 +111,6 @@ class RAJNIViTWrapper(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("residual stream dtype must be torch.float32 or torch.bfloat16")
         self._resid_bf16 = dtype == torch.bfloat16
-        self._weights = self._weights_key = None      # (the LN fold exists on the fp32 stream only: folded copies come and go)
         self._drop_plans()
         return self
 
@@ -167,24 +159,6 @@ class RAJNIViTWrapper(nn.Module):
             self._cls_only_last = bool(on)
             self._drop_plans()
         return self
-
-    def set_ln_fold(self, on: bool = True):
-        """Run norm1 / norm2 as epilogue extras of the GEMMs around them ("LN fold"): the residual
-        epilogue of proj / fc2 also writes a bf16 copy of the stream and per-row statistics, and fc1 / the next qkv
-        compute rstd * (x W'^T - mean * colsum(W')) + b' with gamma / beta folded into W', b'.  Same function; the MFMA
-        sees bf16(x) instead of bf16(LN(x)), so a token's rounding noise grows by sqrt(1 + (mean/std)^2) - read
-        `ln_fold_guard()` after a forward for the largest |mean|/std met.  bf16 models, fp32 residual stream, "model"
-        weight format; silently inactive otherwise."""
-        if bool(on) != self._ln_fold:
-            self._ln_fold = bool(on)
-            self._weights = self._weights_key = None
-            self._drop_plans()
-        return self
-
-    def ln_fold_guard(self) -> int:
-        """Largest floor(|mean| * rstd) over the tokens of every folded LayerNorm since the last reset (0 when the fold
-        is inactive): the factor by which the fold amplified bf16 rounding for the worst token.  Synchronises."""
-        return 0 if self._ln_guard is None else int(self._ln_guard.item())
 
     def trace_scores(self, on: bool = True):
         self._trace_scores = bool(on)
@@ -270,10 +244,6 @@ class RAJNIViTWrapper(nn.Module):
         self._param_list = [p for p in self.m.parameters()]
         return self._param_list
 
-    def _fold_active(self, dtype, desc) -> bool:
-        return (self._ln_fold and dtype == torch.bfloat16 and not self._resid_bf16 and self._weight_format == "model"
-                and desc["C"] % 64 == 0 and desc["hidden"] % 64 == 0)
-
     def _pack_weights(self, device, dtype):
         params = self._all_params()
         # fingerprint of the live weights: storage pointers (`.to()`, `param.data = ...`) and version counters (in-place
@@ -305,8 +275,6 @@ class RAJNIViTWrapper(nn.Module):
         W["head_w"] = pw(m.head.weight)
         W["head_b"] = pv(m.head.bias) if m.head.bias is not None else zeros(desc["num_classes"])
         blocks = []
-        fold = self._fold_active(dtype, desc)
-        W["ln_fold"] = fold
         for blk in self.blocks:
             a = blk.attn
             ls1 = getattr(blk, "ls1", None)
@@ -341,16 +309,6 @@ class RAJNIViTWrapper(nn.Module):
                 ls1=g1, norm2_w=pv(blk.norm2.weight), norm2_b=pv(blk.norm2.bias),
                 fc1_w=fc1_w, fc1_s=fc1_s, fc1_b=fc1_b,
                 fc2_w=fc2_w, fc2_s=fc2_s, fc2_b=pv(blk.mlp.fc2.bias), ls2=g2))
-            if fold:
-                # gamma / beta of norm2 folded into fc1, and of norm1 into qkv (block 0's norm1 follows the patch
-                # embed, not a residual epilogue: it stays a kernel)
-                blocks[-1]["fc1_wf"], blocks[-1]["fc1_bf"], blocks[-1]["fc1_cs"] = ops.fold_layernorm(
-                    blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.norm2.weight, blk.norm2.bias, dtype, device)
-                if hpad != hid:
-                    raise NotImplementedError("ln fold with an MLP width that is not a multiple of 64")
-                if len(blocks) > 1:
-                    blocks[-1]["qkv_wf"], blocks[-1]["qkv_bf"], blocks[-1]["qkv_cs"] = ops.fold_layernorm(
-                        a.qkv.weight, a.qkv.bias, blk.norm1.weight, blk.norm1.bias, dtype, device)
             if self._weight_format == "fp8_mfma":
                 # constants of the hidden-activation bound (rajni_layernorm_fp8): largest row norm of the DEQUANTISED
                 # fc1 weight and largest |bias| as the kernels hold it
@@ -394,8 +352,6 @@ class RAJNIViTWrapper(nn.Module):
                 setattr(cb, name, nat.ptr(bw[name]))
             if self._weight_format == "fp8_mfma":
                 cb.fc1_rownorm_max, cb.fc1_bias_absmax = bw["fc1_rownorm_max"], bw["fc1_bias_absmax"]
-            for name in ("qkv_wf", "qkv_bf", "qkv_cs", "fc1_wf", "fc1_bf", "fc1_cs"):
-                setattr(cb, name, nat.ptr(bw.get(name)))
             if i in self.pruning_schedule:
                 cfg = self.pruning_schedule[i]
                 N = counts[i]
@@ -435,15 +391,10 @@ class RAJNIViTWrapper(nn.Module):
         plan.resid_bf16 = int(self._resid_bf16)
         plan.cls_only_last_block = int(self._cls_only_last)
         plan.act_fp8 = int(self._weight_format == "fp8_mfma")
-        plan.ln_fold = int(bool(W.get("ln_fold")))
-        if plan.ln_fold:
-            if self._ln_guard is None or self._ln_guard.device != torch.device(device):
-                self._ln_guard = torch.zeros(1, dtype=torch.int32, device=device)
-            plan.ln_guard = self._ln_guard.data_ptr()
         nbytes = nat.lib().rajni_vit_workspace_bytes(C.byref(plan))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         plan.workspace, plan.workspace_bytes = ws.data_ptr(), nbytes
-        self._plan = (key, plan, (blocks, tc, ws), bufs, counts)
+        self._plan = (key, plan, (blocks, tc, ws, W), bufs, counts)   # W: a stale optimistic launch keeps its weights alive
         if len(self._plans) >= 4:     # workspaces are large: keep only a few batch shapes alive
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = self._plan
@@ -475,6 +426,9 @@ class RAJNIViTWrapper(nn.Module):
             # otherwise sit in front of every forward.  Packed weights are copies, so a launch on a stale plan reads
             # consistent (old) data; if the check finds a change the forward is simply enqueued again on the new plan
             # and the first result is dropped.  Option setters drop `_plan`, so they always take the slow path.
+            # ONE STREAM PER WRAPPER: the stale launch's workspace and packed weights stay referenced by `cached` until
+            # this function returns and are handed back to the allocator in stream order - a second stream driving the
+            # same wrapper concurrently is not supported (the reference is one-forward-at-a-time too).
             cached = self._plan
             if cached is not None and cached[0][:4] == (B, S, x.device, dtype):
                 logits = launch(cached)

@@ -18,8 +18,7 @@ def test_linear_fuzz_against_torch():
 
 
 def test_linear_fuzz_round2_forms_against_torch():
-    """fp8 x fp8 launches (both tilings, every epilogue, ragged shapes, M from 1 up) and the LayerNorm-fold producer /
-    consumer pair (tools/fuzz_linear_r2.py)."""
+    """fp8 x fp8 launches (both tilings, every epilogue, ragged shapes, M from 1 up; tools/fuzz_linear_r2.py)."""
     spec = importlib.util.spec_from_file_location("fuzz_linear_r2", os.path.join(ROOT, "tools", "fuzz_linear_r2.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -1,6 +1,6 @@
 """attention timing beyond 256 tokens (ViT-L/16 @384 stages: the chunked online-softmax kernel), GPU box only."""
-import sys
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch
 from rajni_amd import ops
 def t(f):

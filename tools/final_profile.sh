@@ -7,7 +7,7 @@
 #   fp8_*.json                      the same three for --weight-format fp8_mfma, plus the configs[4] line
 # Counter passes carry --kernel-trace only (gpurun refuses --pmc together with the other trace domains).
 set -o pipefail
-R=/root/repo
+R="$(cd "$(dirname "$0")/.." && pwd)"
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 """ms per 256-image ViT-B/16 forward (README schedule) with the library named by RAJNI_HIP_LIB; used by tools/ab_libs.sh."""
 import os, sys, time
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch, rajni_amd
 from rajni_amd import timm_shaped as ts
 sched = {3: {"keep_ratio": 0.88, "update": True}, 4: {"keep_ratio": 0.88, "update": True}, 7: {"keep_ratio": 0.80, "update": True}, 8: {"keep_ratio": 0.72, "update": True}}

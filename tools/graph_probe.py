@@ -1,6 +1,6 @@
 """whole-forward hipGraph capture: bit-identical logits and the time it buys (0.4 %: the path is not launch bound)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch, rajni_amd
 from rajni_amd import timm_shaped as ts
 sched = {3: {"keep_ratio": 0.88, "update": True}, 4: {"keep_ratio": 0.88, "update": True}, 7: {"keep_ratio": 0.80, "update": True}, 8: {"keep_ratio": 0.72, "update": True}}

@@ -1,6 +1,6 @@
 """LayerNorm kernel alone on the forward's row counts: microseconds and TB/s (fp32 stream in, bf16 out)."""
-import sys
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch
 from rajni_amd import ops
 for rows in (50432, 38912, 22272):

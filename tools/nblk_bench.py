@@ -1,6 +1,6 @@
 """N-block size of the persistent GEMM tile order (rajni_debug_set_gemm_nblock_bytes) on the ViT-B GEMM shapes."""
 import sys, os
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch
 from rajni_amd import ops, _native as nat
 dev = "cuda"

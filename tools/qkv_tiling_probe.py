@@ -1,6 +1,6 @@
 """QKV / FC1 (bf16-output GEMMs): 256x256 vs 256x128 tiling per token count at batch 256 and 64."""
 import sys, os, math
-sys.path.insert(0, "/root/repo/rajni-vit_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rajni-vit_amd"))
 import torch
 from rajni_amd import ops, _native as nat
 dev = "cuda"

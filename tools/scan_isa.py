@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def kernel_id(mangled):
-    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, TAG, LNF> -> tuple of ints"""
+    """gemm_bf16_tn_stream<EPI, ALOAD, SF32, WM, WN, MI, NS, W8, TAG> -> tuple of ints"""
     m = re.search(r"gemm_bf16_tn_streamI(.*?)EEv", mangled)
     if m is None:          # the fp8 x fp8 kernels: <EPI, SF32, TAG> / <EPI>; every instantiation is dispatched
         m = re.search(r"gemm_f8_tn_(?:stream|wide)I(.*?)EEv", mangled)
@@ -30,7 +30,7 @@ def dispatched(k):
     fused patch loader (a patch embed wider than 1536 channels has K = 3*14*14, not a multiple of 64)."""
     if k[0] == "f8":
         return True
-    epi, aload, sf32, wm, wn, mi, ns, w8, tag, lnf = k
+    epi, aload, sf32, wm, wn, mi, ns, w8, tag = k
     return not ((wm, wn, mi, ns) == (2, 4, 8, 2) and aload == 1)
 
 
