@@ -3,7 +3,9 @@ high-precision checker) written with torch CPU ops, because that is what the ref
 ATen matmuls, `layer_norm`, exact-erf `gelu`, `softmax`.  It exists so that `bench.py`'s `cpu_baseline` times a
 CPU path of the reference's own speed class (numpy's single-threaded elementwise passes made the numpy oracle ~6x
 slower than the reference's CPU run on the same cores).  Shares no code with the reference and does not import it;
-only `tests/` and `bench.py`'s `cpu_baseline` leg import this module.
+only `tests/` and `bench.py`'s baseline legs import this module: `cpu_baseline` (host cores) and
+`pruned_torch_images_per_sec` (the same op graph on stock PyTorch-ROCm kernels on the GPU - what the reference's own
+attention.py:17-60 / model.py:50-59 execute there; a denominator, never the product).
 
 Pinned like the numpy oracle: `tests/test_oracle_golden.py` holds it to the reference-generated fixtures in
 `tests/golden/` (logits, token counts, selections) and to the numpy oracle.
@@ -39,12 +41,17 @@ def keep_count(keep_ratio: float, n_tokens: int) -> int:
     return max(1, int(keep_ratio * (n_tokens - 1)))                           # attention.py:31-32
 
 
-def select_tokens(scores: torch.Tensor, keep: int) -> torch.Tensor:
+def select_tokens(scores: torch.Tensor, keep: int, ref_ops: bool = False) -> torch.Tensor:
     """indices of the `keep` largest patch scores, ascending, +1, CLS prepended (attention.py:34-39) with the
-    DEFINED tie rule of the numpy oracle: larger first, then lower index (stable descending sort; NaN sorts first)."""
-    order = torch.sort(scores[:, 1:], dim=1, descending=True, stable=True).indices[:, :keep]
+    DEFINED tie rule of the numpy oracle: larger first, then lower index (stable descending sort; NaN sorts first).
+    ref_ops=True issues the reference's own op pair instead (torch.topk + sort, attention.py:34-36; tie order
+    unspecified) - used only where the op graph, not the tie rule, is what is being timed (bench.py's GPU baseline)."""
+    if ref_ops:
+        order = torch.topk(scores[:, 1:], keep, dim=1).indices
+    else:
+        order = torch.sort(scores[:, 1:], dim=1, descending=True, stable=True).indices[:, :keep]
     idx = torch.sort(order, dim=1).values + 1
-    return torch.cat([torch.zeros((scores.shape[0], 1), dtype=idx.dtype), idx], dim=1)
+    return torch.cat([torch.zeros((scores.shape[0], 1), dtype=idx.dtype, device=idx.device), idx], dim=1)
 
 
 def _attention(qkv: torch.Tensor, num_heads: int) -> torch.Tensor:
@@ -57,9 +64,14 @@ def _attention(qkv: torch.Tensor, num_heads: int) -> torch.Tensor:
 
 
 def vit_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor, schedule, *, depth: int, num_heads: int,
-                ln_eps: float = 1e-6, forced_keep: Optional[Dict[int, torch.Tensor]] = None, return_trace: bool = False):
+                ln_eps: float = 1e-6, forced_keep: Optional[Dict[int, torch.Tensor]] = None, return_trace: bool = False,
+                ref_op_graph: bool = False):
     """RAJNIViTWrapper.forward (model.py:30-69) + RAJNIAttention.forward (attention.py:17-60) over a timm-named
-    state dict of fp32 CPU tensors.  returns logits, {"token_counts": [...]} (and the per-stage trace)."""
+    state dict of tensors (fp32 on the CPU for the checker; any device / dtype the ATen ops take for the baseline legs
+    of bench.py).  returns logits, {"token_counts": [...]} (and the per-stage trace).
+    ref_op_graph=True issues exactly the reference's ops where this restatement otherwise takes an equal-valued shortcut
+    or a defined rule: torch.topk + sort for the selection (attention.py:34-36) and the final LayerNorm over all tokens
+    (model.py:65) - for timing the reference's op graph (bench.py `pruned_torch_images_per_sec`), not for checking."""
     schedule = {int(k): {"keep_ratio": float(v["keep_ratio"]), "update": bool(v.get("update", True))}
                 for k, v in (schedule or {}).items()}
     with torch.no_grad():
@@ -87,8 +99,8 @@ def vit_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor, schedule, *, 
                 else:
                     full = scores
                 keep = keep_count(cfg["keep_ratio"], x.shape[1])
-                idx = select_tokens(full, keep) if forced_keep is None or i not in forced_keep \
-                    else torch.as_tensor(forced_keep[i], dtype=torch.int64)
+                idx = select_tokens(full, keep, ref_op_graph) if forced_keep is None or i not in forced_keep \
+                    else torch.as_tensor(forced_keep[i], dtype=torch.int64, device=x.device)
                 qkv = torch.gather(qkv, 1, idx.unsqueeze(-1).expand(-1, -1, qkv.shape[-1]))   # attention.py:42-43
                 scores = torch.gather(full, 1, idx)                           # attention.py:58
                 x = torch.gather(x, 1, idx.unsqueeze(-1).expand(-1, -1, C))   # model.py:55-56
@@ -105,7 +117,10 @@ def vit_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor, schedule, *, 
             if p + "ls2.gamma" in sd:
                 h = h * sd[p + "ls2.gamma"]
             x = x + h                                                         # model.py:59
-        x = F.layer_norm(x[:, 0], (C,), sd["norm.weight"], sd["norm.bias"], ln_eps)   # model.py:65 (LN is per token)
+        if ref_op_graph:      # the reference normalises every token and then takes row 0 (model.py:65-66): same values
+            x = F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], ln_eps)[:, 0]
+        else:
+            x = F.layer_norm(x[:, 0], (C,), sd["norm.weight"], sd["norm.bias"], ln_eps)   # model.py:65 (LN is per token)
         logits = F.linear(x, sd["head.weight"], sd["head.bias"])              # model.py:66
     stats = {"token_counts": counts}                                          # model.py:68
     return (logits, stats, trace) if return_trace else (logits, stats)

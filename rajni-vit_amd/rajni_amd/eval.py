@@ -9,9 +9,14 @@ Differences, both deliberate:
   * the device is ALWAYS synchronised around the forward when it is an accelerator - the reference
     compares `device == "cuda"` and so never synchronises when handed a `torch.device` (SURVEY B2);
   * under `torch.distributed` (one process per GPU, images sharded by rank) the counters are joined
-    by ONE all-reduce: SUM of [correct, total, images] and MAX of elapsed seconds, so every rank
-    returns the node-level accuracy and node-level images/sec.  Without a process group it is the
-    single-device function of the reference.
+    by ONE all-reduce (SUM) of a 3 + 2 * world vector: [correct, total, images] followed by one
+    (images, seconds) slot per rank that only its owner fills - so the same collective also tells every
+    rank each rank's own rate; node seconds = MAX over the slots.  Every rank returns the node-level
+    accuracy and node-level images/sec.  Without a process group it is the single-device function of
+    the reference.
+After a call, `evaluate_model.last_stats` holds what the return value cannot (the reference's signature is kept):
+`{"world", "rank", "images", "seconds", "per_rank": [(images, seconds), ...]}` - the multi-GPU diagnosis surface of
+`bench.py` (slowest rank, spread).
 """
 from __future__ import annotations
 
@@ -90,15 +95,26 @@ def evaluate_model(model, dataloader, device="cuda", max_batches=None, warmup=5)
             pbar.set_postfix(acc=f"{100.0 * correct / total:.2f}%",
                              imgs_per_s=f"{total_images / max(total_time, 1e-6):.1f}")
 
+    per_rank = [(total_images, total_time)]
+    world = 1
     if _dist_ready() and torch.distributed.get_world_size() > 1:
+        world = torch.distributed.get_world_size()
         red_dev = device if (_is_accel(device) and torch.distributed.get_backend() == "nccl") else "cpu"
-        counts = torch.tensor([correct, total, total_images], dtype=torch.float64, device=red_dev)
-        elapsed = torch.tensor([total_time], dtype=torch.float64, device=red_dev)
-        torch.distributed.all_reduce(counts, op=torch.distributed.ReduceOp.SUM)
-        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
-        correct, total, total_images = (int(round(v)) for v in counts.tolist())
-        total_time = float(elapsed.item())
+        vec = [0.0] * (3 + 2 * world)
+        vec[0:3] = [correct, total, total_images]
+        vec[3 + 2 * rank], vec[4 + 2 * rank] = total_images, total_time      # this rank's own slot
+        joined = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+        torch.distributed.all_reduce(joined, op=torch.distributed.ReduceOp.SUM)   # the ONE collective (RCCL on device)
+        vals = joined.tolist()
+        correct, total, total_images = (int(round(v)) for v in vals[:3])
+        per_rank = [(int(round(vals[3 + 2 * r])), float(vals[4 + 2 * r])) for r in range(world)]
+        total_time = max(sec for _, sec in per_rank)                               # node time = slowest rank
+    evaluate_model.last_stats = {"world": world, "rank": rank, "images": total_images, "seconds": total_time,
+                                 "per_rank": per_rank}
 
     acc = 100.0 * correct / max(total, 1)                   # eval.py:73
     throughput = total_images / max(total_time, 1e-6)       # eval.py:74
     return acc, throughput
+
+
+evaluate_model.last_stats = None

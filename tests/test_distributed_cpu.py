@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
         # ragged on purpose: rank 0 has 3 batches, rank 1 has 2 (drop_last=False semantics)
         loader = _make_batches(100 + rank, 3 - rank, 8)
         acc, thr = rajni_amd.evaluate_model(_Identity(), loader, device="cpu", max_batches=None, warmup=1)
-        q.put((rank, acc, thr))
+        q.put((rank, acc, thr, rajni_amd.evaluate_model.last_stats))
     finally:
         dist.destroy_process_group()
 
@@ -74,3 +74,11 @@ def test_evaluate_model_world_size_2_gloo():
     assert res[0][1] == pytest.approx(acc1, abs=1e-9)
     assert res[1][1] == pytest.approx(acc1, abs=1e-9)
     assert res[0][2] == pytest.approx(res[1][2], rel=1e-9) and res[0][2] > 0   # same node-level img/s on both ranks
+    # the one all-reduce also carries every rank's own (images, seconds): the multi-GPU diagnosis surface of bench.py
+    for r, (_, _, thr, st) in enumerate(res):
+        assert st["world"] == 2 and st["rank"] == r and st["images"] == 40
+        assert [n for n, _ in st["per_rank"]] == [24, 16]                       # ragged shards: 3 and 2 batches of 8
+        assert all(sec > 0 for _, sec in st["per_rank"])
+        assert st["seconds"] == pytest.approx(max(sec for _, sec in st["per_rank"]))
+        assert thr == pytest.approx(40 / st["seconds"], rel=1e-9)
+    assert res[0][3]["per_rank"] == res[1][3]["per_rank"]

@@ -82,8 +82,23 @@ def test_top1_agreement_on_256_reference_images():
     assert inj["max_abs_dlogit_over_logit_scale"] <= 1e-2
     assert inj["top1_agree"] >= own["top1_agree"]
     assert inj["max_abs_dlogit"] <= own["max_abs_dlogit"]
-    assert (inj["top1_agree"] - free["top1_agree"]) / n <= 0.1
+    # free-running vs injected: a statement in IMAGES, not a 0.1 fraction (north_star's "<= 0.1 top-1 delta" read as 0.1
+    # percentage points of accuracy is unmeasurable without trained weights and labels: DESIGN.md section 2, "unpinned")
     assert free["top1_agree"] >= own["top1_agree"] - 2
+    assert inj["top1_agree"] - free["top1_agree"] <= 8
+
+
+def test_top1_agreement_floor_of_the_fp8_mfma_format():
+    """The opt-in fp8_mfma format (BASELINE configs[4]) has no reference semantics, so its end-to-end price is held as
+    an agreement FLOOR on the same 256 reference images: a wiring bug in the e4m3 path (wrong row scale, wrong hidden
+    bound) costs tens of images, the quantisation itself ~40 (measured r02: 213 injected / 216 free-running of 256; the
+    bf16 default: 252 / 247)."""
+    res = _bench().reference_agreement(torch.device(DEV), weight_format="fp8_mfma")
+    assert "error" not in res, res
+    print("\nreference_agreement fp8_mfma:", res["injected_selections"], res["free_running"])
+    assert res["token_counts_equal"]
+    assert res["injected_selections"]["top1_agree"] >= 205 and res["free_running"]["top1_agree"] >= 205
+    assert res["injected_selections"]["max_abs_dlogit_over_logit_scale"] <= 0.2
 
 
 @pytest.mark.parametrize("cfg_name,fmt", [("vit_micro_patch16_64", "safetensors"), ("deit3_micro_patch16_64", "pt")])

@@ -339,9 +339,10 @@ def test_weight_changes_are_picked_up():
     assert torch.allclose(w(x).float(), y3 + 1.0, atol=2e-2)
 
 
-@pytest.mark.parametrize("name,dtype,fp8", [("micro_fp32", torch.bfloat16, False), ("base224_fp32", torch.bfloat16, False),
-                                            ("deit3_fp32", torch.bfloat16, False), ("base224_fp32", torch.bfloat16, True),
-                                            ("tiny224_fp32", torch.float32, False)])
+@pytest.mark.parametrize("name,dtype,fp8", [("micro_fp32", torch.bfloat16, ""), ("base224_fp32", torch.bfloat16, ""),
+                                            ("deit3_fp32", torch.bfloat16, ""), ("base224_fp32", torch.bfloat16, "fp8"),
+                                            ("base224_fp32", torch.bfloat16, "fp8_mfma"), ("deit3_fp32", torch.bfloat16, "fp8_mfma"),
+                                            ("tiny224_fp32", torch.float32, "")])
 def test_cls_only_last_block_gives_the_same_logits(name, dtype, fp8):
     """`set_last_block_cls_only(True)`: the last block is computed for the CLS row only (the head reads nothing
     else, model.py:65-66).  Same logits as the row-for-row forward up to summation order (the CLS attention
@@ -352,7 +353,7 @@ def test_cls_only_last_block_gives_the_same_logits(name, dtype, fp8):
     model = ts.create_model(cfg, seed=meta["seed"], std=meta["std"], bias_std=meta["bias_std"], round_bf16=True)
     wrapped = rajni_amd.RAJNIViTWrapper(model, meta["schedule"]).to(DEV).to(dtype).eval()
     if fp8:
-        wrapped.set_weight_format("fp8")
+        wrapped.set_weight_format(fp8)
     images = torch.from_numpy(case_images(meta, data)).to(DEV)
     forced = {i: torch.from_numpy(data[f"blk{i}.keep_idx"]).to(DEV) for i in pruned_blocks(meta)}
     wrapped.force_keep_idx(forced)
@@ -363,6 +364,15 @@ def test_cls_only_last_block_gives_the_same_logits(name, dtype, fp8):
     assert wrapped.get_last_stats() == stats
     scale = np.abs(full).max()
     tol = 2e-5 if dtype == torch.float32 else 8e-3          # bf16 logits: one output ulp (2^-8 of the value) may flip
+    if fp8 == "fp8_mfma":
+        # the CLS-row branch runs LN2 -> e4m3 and the fp8 x fp8 fc1 / fc2 on B rows (forward.hip: act_fp8 with
+        # cls_only_last_block): its CLS attention row is not rounded like the packed kernel's, so a few of the last block's
+        # e4m3 codes of the CLS rows flip - one block deep, no compounding.  Held: max within 3e-2, rms within 6e-3 of the scale
+        tol = 3e-2
+        rms = float(np.sqrt(np.mean((fast - full) ** 2)))
+        print(f"\ncls-only + fp8_mfma {name}: max {np.abs(fast - full).max() / scale:.4g} rms {rms / scale:.4g} of the logit scale")
+        assert rms <= 6e-3 * scale
+        assert (fast.argmax(1) == full.argmax(1)).mean() >= 0.9
     assert np.abs(fast - full).max() <= tol * scale, np.abs(fast - full).max() / scale
     if not fp8:
         ref = data["logits"]

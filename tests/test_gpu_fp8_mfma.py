@@ -177,6 +177,15 @@ def _check_against_rule(tag, got, with_act, weights_only, scale):
     assert err <= 1.6 * cost + 1e-2 * scale
     assert dev_cost <= 1.6 * cost + 1e-2 * scale
     assert cost <= 0.2 * scale
+    # The maximum is the chaotic statistic; the rms over all logits is stable from run to run and is what catches a
+    # wiring bug (a wrong x_scale / hidden-scale pointer, a wrong per-block bound constant): two independent
+    # realisations of the same quantisation noise differ by sqrt(2) x the noise rms, a wrong scale by many times that.
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    r_err, r_cost, r_dev = rms(got - with_act), rms(with_act - weights_only), rms(got - weights_only)
+    print(f"   rms: device vs oracle-with-the-rule {r_err / scale:.4g}, the rule's own effect {r_cost / scale:.4g}, device vs "
+          f"weights-only oracle {r_dev / scale:.4g} of the logit scale")
+    assert r_err <= 1.5 * r_cost + 2e-3 * scale           # ~sqrt(2) when device and oracle noise are independent
+    assert 0.5 * r_cost - 2e-3 * scale <= r_dev <= 1.5 * r_cost + 2e-3 * scale    # the device pays the rule's price: not less, not more
 
 
 @pytest.mark.parametrize("batch", [3, 40])

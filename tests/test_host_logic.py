@@ -5,6 +5,7 @@ falling back."""
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -368,3 +369,64 @@ def test_graft_entry_build_runs():
     import importlib
     ge = importlib.import_module("__graft_entry__")
     ge.build()
+
+
+def test_bench_drops_stale_or_foreign_pmc_profiles(tmp_path, monkeypatch):
+    """`roofline.traffic` / `mfma_busy_frac` come from the newest committed PMC profile - only when that profile says it
+    was taken on THIS tree's kernel sources; fp8 profiles never stand in for the bf16 command."""
+    import json
+    bench = _load_bench()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import csrc_fingerprint
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.latest_profile("mfma_pmc.json") == (None, None)
+    (prof / "r03_a_mfma_pmc.json").write_text(json.dumps({"by_bench_class": {}, "csrc_fingerprint": "0" * 16}))
+    assert bench.latest_profile("mfma_pmc.json") == (None, None)                      # other sources: dropped
+    (prof / "r03_b_mfma_pmc.json").write_text(json.dumps({"by_bench_class": {"k": 1}}))
+    assert bench.latest_profile("mfma_pmc.json") == (None, None)                      # no fingerprint at all: dropped
+    good = {"by_bench_class": {"k": 2}, "csrc_fingerprint": csrc_fingerprint()}
+    (prof / "r03_c_mfma_pmc.json").write_text(json.dumps(good))
+    (prof / "r03_d_fp8_mfma_pmc.json").write_text(json.dumps({**good, "by_bench_class": {"f8": 1}}))
+    path, rec = bench.latest_profile("mfma_pmc.json")
+    assert path.endswith("r03_c_mfma_pmc.json") and rec["by_bench_class"] == {"k": 2}  # the fp8 file sorts later but is skipped
+
+
+def test_bench_roofline_picks_the_dominant_gemm_and_prices_proj_against_hbm():
+    bench = _load_bench()
+    prof = {"gemm_bf16_tn<bias>": dict(launches=10, ms=1.0, flops=1e12, bytes=1e9),
+            "gemm_bf16_tn<bias,ls,resid> K<=N": dict(launches=10, ms=3.0, flops=1e12, bytes=9e9)}
+    name, r = bench.gemm_roofline(prof)
+    assert name.endswith("K<=N") and r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert r["achieved"] == pytest.approx(9e9 / 10 / 0.3e-3 / 1e9, rel=1e-3) and r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-4)
+    prof["gemm_f8_tn<bias,gelu,requant>"] = dict(launches=10, ms=5.0, flops=5e12, bytes=1e9)
+    name, r = bench.gemm_roofline(prof)
+    assert name.startswith("gemm_f8") and r["bound"] == "mfma" and r["peak"] == 5000.0
+    assert bench.gemm_roofline({}) == (None, None)
+
+
+def test_pmc_tools_coverage_rules(tmp_path):
+    """tools/pmc_common.py: exact FC1 quantities of a bench.py line, and the rescale / refuse rule of a counter pass."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_common as pc
+    line = {"config": {"dims": {"C": 768, "hidden": 3072, "batch_per_gpu": 256},
+                       "token_counts": [197, 197, 197, 197, 173, 152, 152, 152, 121, 87, 87, 87], "csrc_fingerprint": "abc"}}
+    f = tmp_path / "b.json"
+    f.write_text("noise\n" + json.dumps(line) + "\n")
+    e = pc.expected_fc1(str(f))
+    rows = 256 * (197 * 3 + 173 + 152 * 3 + 121 + 87 * 4) / 12        # tokens AFTER each block's selection
+    assert e["flops"] == pytest.approx(2 * rows * 3072 * 768) and e["out_bytes_bf16"] == pytest.approx(rows * 3072 * 2)
+    assert e["csrc_fingerprint_of_run"] == "abc"
+    assert pc.judge(1.0, "x")[0] == 1.0 and pc.judge(0.985, "x")[0] == 1.0
+    assert pc.judge(0.75, "x")[0] == pytest.approx(1 / 0.75) and "rescaled" in pc.judge(0.75, "x")[1]
+    assert pc.judge(None, "x")[0] == 1.0
+    for bad in (0.3, 1.2):
+        with pytest.raises(SystemExit):
+            pc.judge(bad, "x")
+    assert pc.bench_class(pc.clean("void (anonymous namespace)::wide::gemm_bf16_tn_stream<2, 0, true, 4, 2, 4, 3, false, 1>(GemmParams)")) \
+        == "gemm_bf16_tn<bias,ls,resid> K<=N"
+    assert pc.bench_class(pc.clean("void wide::gemm_bf16_tn_stream<2, 0, true, 4, 2, 4, 3, false, 0>(GemmParams)")) == "gemm_bf16_tn<bias,ls,resid>"
+    assert pc.bench_class("void f8w::gemm_f8_tn_wide<4>(GemmParams)") == "gemm_f8_tn<bias,gelu,requant>"
+    assert pc.bench_class("void layernorm_kernel<float>(...)") is None

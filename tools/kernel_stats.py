@@ -12,7 +12,7 @@ rows = cur.execute("select name, duration from kernels").fetchall()
 agg = {}
 for name, dur in rows:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    if re.search(r"gemm_bf16_tn_stream<2,.*, 1, (?:true|false)>\(", name):     # TAG = 1: the K <= N residual launches (projection)
+    if re.search(r"gemm_bf16_tn_stream<2,.*, 1>\(", name):     # TAG = 1: the K <= N residual launches (projection)
         name += " [K<=N: bench class gemm_bf16_tn<bias,ls,resid> K<=N]"
     elif re.search(r"gemm_bf16_tn_stream<2,", name):
         name += " [K>N: bench class gemm_bf16_tn<bias,ls,resid>]"
