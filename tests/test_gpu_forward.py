@@ -367,11 +367,11 @@ def test_cls_only_last_block_gives_the_same_logits(name, dtype, fp8):
     if fp8 == "fp8_mfma":
         # the CLS-row branch runs LN2 -> e4m3 and the fp8 x fp8 fc1 / fc2 on B rows (forward.hip: act_fp8 with
         # cls_only_last_block): its CLS attention row is not rounded like the packed kernel's, so a few of the last block's
-        # e4m3 codes of the CLS rows flip - one block deep, no compounding.  Held: max within 3e-2, rms within 6e-3 of the scale
-        tol = 3e-2
+        # e4m3 codes of the CLS rows flip - one block deep, no compounding (measured: max 4-5e-3, rms 1.1e-3 of the scale).
+        tol = 1.5e-2
         rms = float(np.sqrt(np.mean((fast - full) ** 2)))
         print(f"\ncls-only + fp8_mfma {name}: max {np.abs(fast - full).max() / scale:.4g} rms {rms / scale:.4g} of the logit scale")
-        assert rms <= 6e-3 * scale
+        assert rms <= 3e-3 * scale
         assert (fast.argmax(1) == full.argmax(1)).mean() >= 0.9
     assert np.abs(fast - full).max() <= tol * scale, np.abs(fast - full).max() / scale
     if not fp8:

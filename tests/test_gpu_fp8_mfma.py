@@ -184,8 +184,9 @@ def _check_against_rule(tag, got, with_act, weights_only, scale):
     r_err, r_cost, r_dev = rms(got - with_act), rms(with_act - weights_only), rms(got - weights_only)
     print(f"   rms: device vs oracle-with-the-rule {r_err / scale:.4g}, the rule's own effect {r_cost / scale:.4g}, device vs "
           f"weights-only oracle {r_dev / scale:.4g} of the logit scale")
-    assert r_err <= 1.5 * r_cost + 2e-3 * scale           # ~sqrt(2) when device and oracle noise are independent
-    assert 0.5 * r_cost - 2e-3 * scale <= r_dev <= 1.5 * r_cost + 2e-3 * scale    # the device pays the rule's price: not less, not more
+    # measured (r03, five cases): r_err / r_cost 0.78-1.13, r_dev / r_cost 0.96-1.20
+    assert r_err <= 1.35 * r_cost + 2e-3 * scale          # <= sqrt(2): device and oracle noise are partly correlated
+    assert 0.6 * r_cost - 2e-3 * scale <= r_dev <= 1.4 * r_cost + 2e-3 * scale    # the device pays the rule's price: not less, not more
 
 
 @pytest.mark.parametrize("batch", [3, 40])
