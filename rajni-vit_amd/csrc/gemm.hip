@@ -125,6 +125,18 @@ __device__ __forceinline__ void store1(void* base, long off, float v) {
   else reinterpret_cast<bf16_t*>(base)[off] = f2bf(v);
 }
 
+// FC1's hidden activations (the largest tensor of a block: written once, read once by FC2) are stored NON-TEMPORAL:
+// measured on the whole forward (tools/ab_libs.sh, round 3) FC1 -2..-3 %, +0.5 % end to end.  The rest of that experiment -
+// keeping the fp32 residual stream resident in the 256 MiB Infinity Cache by also moving the QKV output and FC2's X-operand
+// DMA past it - was negative: non-temporal X loads cost FC2 +15 % (its row panels are re-read by six column tiles out of L2),
+// non-temporal QKV stores cost attention +4 %; neither made the residual epilogues or LayerNorm faster.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store_u4(void* ptr, const uint4& v) {
+  if constexpr (NT) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(ptr));
+  else *reinterpret_cast<uint4*>(ptr) = v;
+}
+
 // One output row m, columns nb..nb+15 (v = accumulators + bias on entry).
 // SF32: the residual-stream tensors this launch touches (R and Y of RESID, Y of PATCH) are fp32.
 // v[0..7] are columns nbA..nbA+7 and v[8..15] columns nbB..nbB+7 of output row m (nbB = nbA + 32: the
@@ -380,8 +392,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           }
         }
         bf16_t* row = Y + (long)(m_base + mi * 16 + l15) * p.ldc;
-        *reinterpret_cast<uint4*>(row + ca) = pack8(v);
-        *reinterpret_cast<uint4*>(row + cb) = pack8(v + 8);
+        store_u4<EPI == EPI_GELU>(row + ca, pack8(v));
+        store_u4<EPI == EPI_GELU>(row + cb, pack8(v + 8));
       }
       return;
     }
@@ -1222,6 +1234,7 @@ int g_force_f8_tiling = 0;   // test hook: 0 by shape, 1 = 256 x 128 always, 2 =
 template <int EPI, bool SF32>
 int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
   const int cus = rajni_num_cus();
+  p.stamps = rajni_g_stamps;
   if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU8) {
     const bool wide_ok = p.K >= 384;
     // measured on ViT-B at batch 256 (K = 768: 6 K steps per tile, so per-tile costs weigh double against the bf16

@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
   int st = 0;   // LDS stage of the current K step
 
   while (true) {
+#ifdef RAJNI_GEMM_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
     int tm, tn;
     tile_mn(tile, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -224,6 +227,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
     }
     kstep(F{}, F{}, nk - 2);
     kstep(T{}, T{}, nk - 1);
+#ifdef RAJNI_GEMM_STAMPS
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][MI - 1][3]));
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue (the next tile's first loads are in flight): dequantise rows, then the shared tile epilogues
     // (the fence keeps hipcc from hoisting the epilogue's loads among the last step's MFMAs, where their targets
@@ -306,7 +313,20 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
       epilogue_tile<EPI, SF32, MI, true>(p, acc, m_base, n0w, l15, g, pre, 0, inter);
     }
     __builtin_amdgcn_sched_barrier(0);    // keep the fragment reads below the epilogue (hoisted, they cost it 64 VGPRs)
+#ifdef RAJNI_GEMM_STAMPS
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
     if (more) read_frags(xa, wa, st);     // the next tile's K-tile 0 (landed and barrier-passed in the last step)
+#ifdef RAJNI_GEMM_STAMPS
+    if (p.stamps != nullptr && wave == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        unsigned long long* o = p.stamps + (size_t)tile * 4;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+      }
+    }
+#endif
     prev_full = inter;
     if (!more) break;
     v = vn;
@@ -475,6 +495,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
   int st = 0;
 
   while (true) {
+#ifdef RAJNI_GEMM_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
     int tm, tn;
     tile_mn(tile, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -515,6 +538,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
     };
     for (int kt = 0; kt < nk - 1; ++kt) kstep(F{}, kt);
     kstep(T{}, nk - 1);
+#ifdef RAJNI_GEMM_STAMPS
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[NT - 1][MT - 1][15]));
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue
     __builtin_amdgcn_sched_barrier(0);
@@ -577,7 +604,20 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RAJNI_GEMM_STAMPS
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
     if (more) read_ks0(st);      // the next tile's (K-tile 0, ks0): landed and barrier-passed in the last step
+#ifdef RAJNI_GEMM_STAMPS
+    if (p.stamps != nullptr && wave == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        unsigned long long* o = p.stamps + (size_t)tile * 4;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+      }
+    }
+#endif
     prev_full = inter;
     if (!more) break;
     v = vn;

@@ -14,4 +14,13 @@ for r in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): m(x)
     torch.cuda.synchronize(); ts_.append((time.perf_counter() - t0) / 10 * 1e3)
-print(f"{os.environ.get('RAJNI_HIP_LIB','default')[-20:]:22s} min {min(ts_):.3f} ms  med {sorted(ts_)[4]:.3f} ms")
+print(f"{os.environ.get('RAJNI_HIP_LIB','default')[-20:]:22s} min {min(ts_):.3f} ms  med {sorted(ts_)[4]:.3f} ms", end="")
+# per kernel class (HIP events on the launch stream), us per forward
+from rajni_amd import _native as nat
+nat.profile_reset(); nat.profile_enable(0xFFFF)
+for _ in range(5): m(x)
+torch.cuda.synchronize(); nat.profile_enable(0)
+pr = nat.profile_collect()
+short = {"gemm_bf16_tn<bias>": "qkv", "gemm_bf16_tn<bias,gelu>": "fc1", "gemm_bf16_tn<bias,ls,resid>": "fc2", "gemm_bf16_tn<bias,ls,resid> K<=N": "proj",
+         "layernorm_kernel": "ln", "attn_bf16_d64": "attn", "score_select_kernel<fused>": "score", "gemm_bf16_tn<patch>": "patch"}
+print("  | us/forward: " + "  ".join(f"{short.get(k, k[:14])} {v['ms'] / 5 * 1e3:.0f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1]['ms'])))
