@@ -193,10 +193,17 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
         if (lane == 0) { hstat[h] = mx; hstat[H + h] = se; }
       }
       __syncthreads();
-      for (int n = tid; n < N; n += SS_THREADS) {
+      // A_cls[n] = (1/H) sum_h exp(l[h][n] - max_h) / sum_h: FOUR lanes per token, lane q sums heads q, q + 4, ... in head
+      // order, the four partial sums join in a fixed quad tree (one lane per token left 80 % of the workgroup idle
+      // through 12 dependent exp / divide steps: 2.5k of the kernel's 79k cycles at 197 tokens)
+      for (int n0 = 0; n0 < N; n0 += SS_THREADS / 4) {
+        const int n = n0 + (tid >> 2), q = tid & 3;
         float s = 0.f;
-        for (int h = 0; h < H; ++h) s += __expf(region[h * N + n] - hstat[h]) / hstat[H + h];
-        acls[n] = s / (float)H;
+        if (n < N)
+          for (int h = q; h < H; h += 4) s += __expf(region[h * N + n] - hstat[h]) / hstat[H + h];
+        s = dpp_add<0xB1>(s);
+        s = dpp_add<0x4E>(s);
+        if (n < N && q == 0) acls[n] = s / (float)H;
       }
     };
 
@@ -269,8 +276,18 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     // ---- token mean of vbar, fixed-order two-level sum (importance.py:25)
     {
       const int d = tid % D, prt = tid / D, nparts = SS_PART / D;      // threads past nparts * D idle
-      float s = 0.f;
-      for (int n = prt < nparts ? prt : N; n < N; n += nparts) s += vbar[n * D + d];
+      // four independent chains (tokens prt, prt + nparts, ...: chain = step mod 4), joined in a fixed tree: one
+      // dependent LDS-read + add chain of N / nparts = 25 steps was 3k of the kernel's cycles
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int n = prt < nparts ? prt : N;
+      for (; n + 3 * nparts < N; n += 4 * nparts) {
+        s0 += vbar[n * D + d]; s1 += vbar[(n + nparts) * D + d];
+        s2 += vbar[(n + 2 * nparts) * D + d]; s3 += vbar[(n + 3 * nparts) * D + d];
+      }
+      if (n < N) s0 += vbar[n * D + d];
+      if (n + nparts < N) s1 += vbar[(n + nparts) * D + d];
+      if (n + 2 * nparts < N) s2 += vbar[(n + 2 * nparts) * D + d];
+      const float s = (s0 + s1) + (s2 + s3);
       if (prt < nparts) part[prt * D + d] = s;
       __syncthreads();
       if (tid < D) {
@@ -306,6 +323,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     __syncthreads();
     SS_STAMP(4);
     // ---- mu, unbiased std + eps over tokens   (importance.py:28-29)
+    //      (every wave reducing the norms itself - one barrier and the broadcast fewer - was measured: +400 cycles)
     if (wave == 0) {
       float s = 0.f;
       for (int n = lane; n < N; n += 64) s += sc[n];
@@ -350,14 +368,38 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
   int running = 0;
   // tpt = 1, 2, 4 or 8 lanes share a token's rank count (each a slice of the j range, summed by shuffles): with
   // 197 tokens one lane per token left 60 % of the workgroup idle through a 196-step loop
-  // ranking keys (NaN = +inf) in LDS once - the A_cls region is dead by now - so that the count loop is a 16-byte
-  // broadcast read and four compares per step (one scalar LDS read + NaN test per element, un-pipelined, made this
-  // phase 9 us of the kernel: 100 dependent LDS round trips per lane)
-  float* keys = acls;
-  for (int n = tid; n < N; n += SS_THREADS) keys[n] = rank_key(sc[n]);
-  __syncthreads();
   const int tpt = (N - 1) * 8 <= SS_THREADS ? 8 : (N - 1) * 4 <= SS_THREADS ? 4 : (N - 1) * 2 <= SS_THREADS ? 2 : 1;
   const int per_iter = SS_THREADS / tpt, sl = tid & (tpt - 1);
+  // The count loop is VALU bound (N^2 compares over 4 SIMDs: stamps put it at 14k of the kernel's 88k cycles at 197
+  // tokens, 95k of 297k at 577, when a compare was ~8 instructions: two range tests, >, ==, index test, or / and / add).
+  // 16-bit scores (the bf16 path): ONE unsigned compare per pair on a packed key
+  //     key32[j] = sortable16(score_j) << 16 | (0xFFFF - j)        (NaN = +inf, -0 = +0; N <= 65535)
+  // "j beats i" (larger score, or equal score and lower index - the defined tie rule) <=> key32[j] > key32[i], and the
+  // CLS slot and the padding hold 0 (below every real key), so slices need no range tests: v_cmp + add-with-carry.
+  // fp32 scores keep the float compare (the accuracy path).
+  constexpr bool PACKED = sizeof(T) == 2;
+  float* keys = acls;                                         // fp32 path: ranking keys (NaN = +inf), A_cls is dead
+  unsigned* keys32 = reinterpret_cast<unsigned*>(region);     // packed path: the logits' region is dead (>= N + 4 * tpt + 4 words)
+  const int chunks = (N + 3) >> 2, cps = (chunks + tpt - 1) / tpt;   // 16-byte chunks of keys; per slice
+  const int cstride = cps | 1;     // slices an ODD number of chunks apart: the tpt broadcast reads of a step hit distinct banks
+  if constexpr (PACKED) {
+    for (int w = tid; w < cstride * tpt * 4; w += SS_THREADS) {
+      const int slw = w / (cstride * 4), off = w - slw * cstride * 4;
+      const int n = off < cps * 4 ? slw * cps * 4 + off : N;     // token of word w (padding words: none)
+      unsigned k = 0;
+      if (n >= 1 && n < N) {
+        unsigned u = __float_as_uint(rank_key(sc[n]));
+        u = (u == 0x80000000u) ? 0u : u;                            // -0 ranks as +0
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);             // monotone float -> unsigned
+        k = (u & 0xFFFF0000u) | (unsigned)(0xFFFF - n);
+      }
+      keys32[w] = k;
+    }
+  } else {
+    for (int n = tid; n < N; n += SS_THREADS) keys[n] = rank_key(sc[n]);
+  }
+  __syncthreads();
+  SS_STAMP(7);
   const int slice = (N - 1 + tpt - 1) / tpt;
   for (int base_i = 1; base_i < N; base_i += per_iter) {
     const int i = base_i + tid / tpt;
@@ -366,16 +408,28 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     int rank = 0;
     if (valid) {
       si = sc[i];
-      const float ki = keys[i];
-      const int j0 = 1 + sl * slice, j1 = j0 + slice < N ? j0 + slice : N;
-      // j beats i when its key is larger, or equal with a lower index (the defined tie rule)
-      auto beats = [&](float kj, int j) { return (j >= j0 && j < j1 && (kj > ki || (kj == ki && j < i))) ? 1 : 0; };
+      if constexpr (PACKED) {
+        const int si_ = i / (cps * 4);                                  // slice and word that hold token i's key
+        const unsigned ki = keys32[si_ * cstride * 4 + (i - si_ * cps * 4)];
+        const uint4* kp = reinterpret_cast<const uint4*>(keys32) + sl * cstride;
 #pragma unroll 4
-      for (int j = j0 & ~3; j < j1; j += 4) {    // aligned 16-byte reads; entries outside [j0, j1) are masked
-        const float4 k4 = *reinterpret_cast<const float4*>(keys + j);   // may run 3 floats into `sc`: masked
-        rank += beats(k4.x, j) + beats(k4.y, j + 1) + beats(k4.z, j + 2) + beats(k4.w, j + 3);
+        for (int c = 0; c < cps; ++c) {
+          const uint4 k4 = kp[c];
+          rank += (k4.x > ki) + (k4.y > ki) + (k4.z > ki) + (k4.w > ki);
+        }
+      } else {
+        const float ki = keys[i];
+        const int j0 = 1 + sl * slice, j1 = j0 + slice < N ? j0 + slice : N;
+        // j beats i when its key is larger, or equal with a lower index (the defined tie rule)
+        auto beats = [&](float kj, int j) { return (j >= j0 && j < j1 && (kj > ki || (kj == ki && j < i))) ? 1 : 0; };
+#pragma unroll 4
+        for (int j = j0 & ~3; j < j1; j += 4) {    // aligned 16-byte reads; entries outside [j0, j1) are masked
+          const float4 k4 = *reinterpret_cast<const float4*>(keys + j);   // may run 3 floats into `sc`: masked
+          rank += beats(k4.x, j) + beats(k4.y, j + 1) + beats(k4.z, j + 2) + beats(k4.w, j + 3);
+        }
       }
     }
+    SS_STAMP(8);
     if (tpt >= 2) rank += __shfl_xor(rank, 1, 64);
     if (tpt >= 4) rank += __shfl_xor(rank, 2, 64);
     if (tpt >= 8) rank += __shfl_xor(rank, 4, 64);
@@ -383,6 +437,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     const unsigned long long bal = __ballot(kept);
     if (lane == 0) wcount[wave] = __popcll(bal);
     __syncthreads();
+    SS_STAMP(9);
     int prefix = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < SS_THREADS / 64; ++w) {
@@ -397,6 +452,7 @@ __global__ void __launch_bounds__(SS_THREADS) score_select_kernel(const ScoreArg
     }
     running += total;
     __syncthreads();
+    SS_STAMP(10);
   }
   if (tid == 0) {
     kout[0] = 0;
