@@ -411,13 +411,15 @@ def test_pmc_tools_coverage_rules(tmp_path):
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_common as pc
-    line = {"config": {"dims": {"C": 768, "hidden": 3072, "batch_per_gpu": 256},
+    line = {"config": {"dims": {"C": 768, "hidden": 3072, "batch_per_gpu": 256, "classes": 1000},
                        "token_counts": [197, 197, 197, 197, 173, 152, 152, 152, 121, 87, 87, 87], "csrc_fingerprint": "abc"}}
     f = tmp_path / "b.json"
     f.write_text("noise\n" + json.dumps(line) + "\n")
     e = pc.expected_fc1(str(f))
     rows = 256 * (197 * 3 + 173 + 152 * 3 + 121 + 87 * 4) / 12        # tokens AFTER each block's selection
-    assert e["flops"] == pytest.approx(2 * rows * 3072 * 768) and e["out_bytes_bf16"] == pytest.approx(rows * 3072 * 2)
+    assert e["flops"] == pytest.approx(2 * rows * 3072 * 768)
+    qkv = 256 * (197 * 4 + 173 + 152 * 3 + 121 + 87 * 3) * 2304 * 2          # QKV runs on the tokens ENTERING each block
+    assert e["qkv_out_bytes"] == pytest.approx(qkv / 12) and e["qkv_out_bytes_with_head"] == pytest.approx((qkv + 256 * 1000 * 2) / 13)
     assert e["csrc_fingerprint_of_run"] == "abc"
     assert pc.judge(1.0, "x")[0] == 1.0 and pc.judge(0.985, "x")[0] == 1.0
     assert pc.judge(0.75, "x")[0] == pytest.approx(1 / 0.75) and "rescaled" in pc.judge(0.75, "x")[1]

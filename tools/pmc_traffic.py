@@ -9,13 +9,13 @@ Counters are in KiB; FETCH_SIZE is doubled on gfx950 (it tallies 128-byte reques
 MI355X_MICROARCH.md, HBM / rocprofv3 section).  These are L2 <-> fabric bytes: Infinity Cache hits included.
 
 Self-check (tools/pmc_common.py): with the bench.py line of a pass given, `coverage` = measured / exact output bytes of
-the FC1 launches - through WRITE_SIZE in the write pass and through TCC_EA0_WRREQ_64B_sum (64-byte write requests: what
+the QKV launches - through WRITE_SIZE in the write pass and through TCC_EA0_WRREQ_64B_sum (64-byte write requests: what
 16-byte-per-lane streaming stores become) in the fetch pass; a pass below 0.98 is rescaled, below 0.5 refused."""
 import json
 import sqlite3
 import sys
 
-from pmc_common import CHECK_CLASSES, bench_class, clean, expected_fc1, judge, provenance
+from pmc_common import WRITE_CHECK_CLASSES, bench_class, clean, expected_fc1, judge, provenance
 
 
 def per_kernel(db_path, counter):
@@ -46,15 +46,15 @@ def main():
     exp = expected_fc1(sys.argv[3]) if len(sys.argv) > 3 else None
     cov_w = cov_f = None
     if exp:
-        for cls, key in zip(CHECK_CLASSES, ("out_bytes_bf16", "out_bytes_e4m3")):
+        for cls, key in zip(WRITE_CHECK_CLASSES, ("qkv_out_bytes_with_head", "qkv_out_bytes")):
             w = class_mean(write, (cls,), 1024.0)
             if w is not None and cov_w is None:
                 cov_w = w / exp[key]
             f = class_mean(fetch_wr64, (cls,), 64.0)
             if f is not None and cov_f is None:
                 cov_f = f / exp[key]
-    scale_w, note_w = judge(cov_w, "write pass (WRITE_SIZE of the FC1 launches vs rows x hidden x element size)")
-    scale_f, note_f = judge(cov_f, "fetch pass (TCC_EA0_WRREQ_64B_sum x 64 of the FC1 launches vs the same)")
+    scale_w, note_w = judge(cov_w, "write pass (WRITE_SIZE of the QKV-class launches vs rows x 3C x 2 bytes)")
+    scale_f, note_f = judge(cov_f, "fetch pass (TCC_EA0_WRREQ_64B_sum x 64 of the QKV-class launches vs the same)")
     by_kernel, by_class = {}, {}
     for name, (n, kib) in fetch.items():
         if name.startswith("void at::") or "rocclr" in name:
