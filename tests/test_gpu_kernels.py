@@ -248,6 +248,35 @@ def test_select_degenerate_rows():
     assert 7 in idx[0].tolist()
 
 
+@pytest.mark.parametrize("N", [2, 5, 64, 129, 197, 258, 577, 1030])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_select_special_values_and_slice_boundaries(N, dt):
+    """The bf16 path ranks on packed 32-bit keys (sortable16(score) << 16 | 0xFFFF - index): signs, +-0, +-inf, NaN, denormals
+    and runs of ties - placed so that they straddle the slice and 16-byte chunk boundaries of the count loop for every
+    lanes-per-token setting (N = 2 ... 1030: 8, 4, 2 and 1 lanes per token; several rank-loop iterations) - must select
+    exactly what the defined rule selects (larger first, then lower index; NaN = +inf; -0 == +0), every keep count class."""
+    rng = np.random.default_rng(N)
+    B = 6
+    vals = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38, 3.0e-3, 3.0e-3, 2.0 ** -7, -(2.0 ** -7), 0.5, 0.5],
+                    dtype=np.float32)
+    s = rng.choice(vals, size=(B, N)).astype(np.float32)
+    s[1] = np.where(rng.random(N) < 0.5, np.float32(0.0), np.float32(-0.0))     # only zeros of both signs: index order decides
+    s[2] = rng.standard_normal(N).astype(np.float32)                              # plain signed values
+    s[2, :: 3] = s[2, 0]                                                          # ... with a long run of ties
+    if dt == "bf16":
+        s = bf16_round_np(s)
+        t = torch.from_numpy(s).to(DEV).to(torch.bfloat16)
+    else:
+        t = torch.from_numpy(s).to(DEV)
+    for keep in sorted({1, max(1, (N - 1) // 2), max(1, N - 2), N - 1}):
+        idx, nxt = ops.select_topk(t, keep)
+        want = orc.select_tokens(s, keep)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want, err_msg=f"N={N} keep={keep} {dt}")
+        got_next = nxt.float().cpu().numpy()
+        exp_next = np.take_along_axis(s, want, axis=1)
+        assert np.array_equal(got_next, exp_next, equal_nan=True)
+
+
 @pytest.mark.parametrize("B,N,H", [(4, 197, 12), (2, 577, 16), (3, 17, 2), (2, 87, 3)])
 def test_score_select_fused(B, N, H):
     rng = np.random.default_rng(N * H)
