@@ -329,6 +329,50 @@ struct ResidPrefetch {
   float4 r[MI][4];
   bool valid;
 };
+// Round 3 - the ACCESS SHAPE of this epilogue was its bottleneck (tools/pull_probe.hip: 128 KB of loads then 128 KB of stores
+// per workgroup, every CU at once / 16 CUs only, cycles per tile): the accumulator layout's shape - a wave instruction = 16 rows
+// x 64 bytes, four lanes per row - 14.7 k / 10.8 k; full lines - 8 rows x 128 bytes per instruction - 11.1 k / 3.6 k.  One CU
+// pulls 64-byte pieces at a third of the rate of whole 128-byte lines, whatever the other CUs do.  ROWMAJOR (the persistent
+// 256 x 128 tiling, which has 16 KiB of LDS to spare): residual rows are loaded, and outputs stored, 8 rows x 128 bytes at a
+// time - row group mi, column half hc, instruction j: row 16 mi + 8 j + (lane >> 3), columns 32 hc + 4 (lane & 7) .. + 3 - and
+// the accumulators reach that layout through a 2 KiB per-wave LDS transpose (epilogue_tile).
+template <int MI>
+__device__ __forceinline__ void prefetch_resid_rowmajor(const GemmParams& p, ResidPrefetch<MI>& pre, int m_base, int n0w, int lane) {
+  pre.valid = false;
+  if (n0w + 64 <= p.N && m_base + MI * 16 <= p.M) {     // interior tile: no guards needed
+    const float* R = reinterpret_cast<const float*>(p.R) + n0w + 4 * (lane & 7);
+    // (the gathered / direct choice is hoisted over the whole block: a per-load "index or load" select makes hipcc
+    //  branch around every load and wait vmcnt(0) behind each - eight serialised L2 round trips inside the K loop)
+    long roff[MI][2];
+    if (p.ridx != nullptr) {
+      int gi[MI][2];                                      // gathered-row indices first, all in flight together
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gi[mi][j] = p.ridx[m_base + mi * 16 + j * 8 + (lane >> 3)];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int m = m_base + mi * 16 + j * 8 + (lane >> 3);
+          roff[mi][j] = ((long)(m / p.r_np) * p.r_nsrc + gi[mi][j]) * p.ldr;
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) roff[mi][j] = (long)(m_base + mi * 16 + j * 8 + (lane >> 3)) * p.ldr;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        pre.r[mi][j] = *reinterpret_cast<const float4*>(R + roff[mi][j]);            // column half 0
+        pre.r[mi][2 + j] = *reinterpret_cast<const float4*>(R + roff[mi][j] + 32);   // column half 1
+      }
+    pre.valid = true;
+  }
+}
 template <int EPI, bool SF32, int MI>
 __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetch<MI>& pre, int m_base, int n0w,
                                                int l15, int g) {
@@ -354,9 +398,56 @@ __device__ __forceinline__ void prefetch_resid(const GemmParams& p, ResidPrefetc
 template <int EPI, bool SF32, int MI, bool W8 = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n0w,
                                               int l15, int g, ResidPrefetch<MI>& pre, int m_lo = 0,
-                                              bool interior = false) {
+                                              bool interior = false, char* scratch = nullptr) {
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
+  if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
+    if (!W8 && scratch != nullptr && pre.valid) {
+      // ROWMAJOR epilogue of an interior tile (see prefetch_resid_rowmajor): per row group and column half, the wave's 16 x 32
+      // accumulator block goes through its 2 KiB LDS scratch - written in the MFMA layout (lane = row l15, columns 4 g..),
+      // read back as 8 rows x 128 bytes per instruction (16-byte chunks XOR-swizzled by the row pair: conflict free both
+      // ways) - meets the residual rows loaded in that shape, and leaves as whole 128-byte lines.
+      const int lane = g * 16 + l15;
+      const int rr = lane >> 3, cc = lane & 7;                    // read-back: row rr (+ 8 j), 16-byte chunk cc of the half
+      float bias[2][4], gam[2][4];
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0w + 32 * hc + 4 * cc + e;
+          bias[hc][e] = p.bias != nullptr ? p.bias[n] : 0.f;
+          gam[hc][e] = p.gamma != nullptr ? p.gamma[n] : 1.f;
+        }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load so far has landed, on every path (see the note below)
+      float* Y = reinterpret_cast<float*>(p.Y) + n0w + 4 * cc;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {   // n-tile 2 hc + q: chunk 4 q + g of row l15
+            const int slot = (4 * q + g) ^ ((l15 >> 1) & 3);
+            *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + slot * 16) = __builtin_bit_cast(bf16x8, acc[2 * hc + q][mi]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = 8 * j + rr, slot = cc ^ ((row >> 1) & 3);
+            const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
+            const float4 r = pre.r[mi][2 * hc + j];
+            float4 o;
+            o.x = fmaf(gam[hc][0], a[0] + bias[hc][0], r.x);
+            o.y = fmaf(gam[hc][1], a[1] + bias[hc][1], r.y);
+            o.z = fmaf(gam[hc][2], a[2] + bias[hc][2], r.z);
+            o.w = fmaf(gam[hc][3], a[3] + bias[hc][3], r.w);
+            *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + row) * p.ldc + 32 * hc) = o;
+          }
+          __builtin_amdgcn_wave_barrier();   // the block's reads are issued before the next block's writes (LDS is in order per wave)
+        }
+      return;
+    }
+  }
   if constexpr (MAP == MAP_SEC && (EPI == EPI_BIAS || EPI == EPI_GELU)) {
     // interior tile of a bf16-output launch (QKV, FC1 - the bulk of all tiles): no row or column guard, the
     // lane's 2 x 8 columns of bias (and fp8 scale) as four 16-byte loads, two 16-byte stores per row.  The
@@ -564,6 +655,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // fp32-stream RESID launches of the 256 x 128 tiling: full-line residual loads / output stores through a 2 KiB per-wave
+  // LDS transpose behind the stages (host: RESID_SCRATCH_BYTES more dynamic LDS) - see prefetch_resid_rowmajor
+  // (bf16 weights: with the fp8-weight scale on top the instantiation spills - it keeps the accumulator-layout epilogue)
+  constexpr bool ROWMAJOR = nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4 && !W8;
 
   // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
   //      (fp8 W: a piece = 16 rows x 64 B, lane -> row lane>>2, 16-byte unit lane&3)
@@ -769,7 +864,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
       if (kt == nk - NS && more) advance(tile, xcd_tile_of(vn, p.total_tiles));
       const int dkt = kt + NS < nk ? kt + NS : kt + NS - nk;
       const int st1 = st + 1 == NS ? 0 : st + 1;
-      if (kt == nk - 1 && inter) prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
+      if (kt == nk - 1 && inter) {
+        if constexpr (ROWMAJOR) prefetch_resid_rowmajor<MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, lane);
+        else prefetch_resid<EPI, SF32, MI>(p, pre, m0 + wm * (MI * 16), n0 + wn * 64, l15, g);
+      }
       half(F{}, T{}, xa, wa, xb, wb, st, 1, 0, 0);
       // my reads of stage st are done and my DMA pieces of step kt+1 have landed ...
       if (NSTORE > 0 && kt == 0 && prev_full) wait_step<WBASE + NSTORE>();
@@ -786,7 +884,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
 #endif
 
     // ---- epilogue (the next tile's first loads are in flight)
-    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter);
+    epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter,
+                                     ROWMAJOR ? smem + C::LDS_BYTES + wave * 2048 : nullptr);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1205,17 +1304,19 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     }
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>, C::LDS_BYTES, attr[2])) != RAJNI_OK) return rc;
+    // fp32-stream RESID: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 = 160 KiB)
+    constexpr int lds = C::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID && !W8) ? 8 * 2048 : 0);
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>, lds, attr[2])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, C::LDS_BYTES, attr[4])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, lds, attr[4])) != RAJNI_OK) return rc;
     p.total_tiles = t256;
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 128, p.K, 2, cus);
     const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>), dim3(grid), dim3(512), lds, s, p);
     } else {
-      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>), dim3(grid), dim3(512), lds, s, p);
     }
   } else {
     constexpr int lds = small::LDS_BYTES;
