@@ -340,10 +340,15 @@ template <int MI>
 __device__ __forceinline__ void prefetch_resid_rowmajor(const GemmParams& p, ResidPrefetch<MI>& pre, int m_base, int n0w, int lane) {
   pre.valid = false;
   if (n0w + 64 <= p.N && m_base + MI * 16 <= p.M) {     // interior tile: no guards needed
+    // (opaque to loop-invariant code motion: hoisted out of the persistent tile loop, the lane's 64-bit base pointers of
+    //  R and Y were two more registers live across the K loop - the fp8-weight instantiation spilled them)
+    asm volatile("" : "+v"(lane));
     const float* R = reinterpret_cast<const float*>(p.R) + n0w + 4 * (lane & 7);
     // (the gathered / direct choice is hoisted over the whole block: a per-load "index or load" select makes hipcc
     //  branch around every load and wait vmcnt(0) behind each - eight serialised L2 round trips inside the K loop)
-    long roff[MI][2];
+    // (element offsets as 32-bit ints: the host sends tensors of 2^31 elements or more to the 128 x 128 tiling - eight
+    //  64-bit offsets held across the last K step were what made the fp8-weight instantiation spill)
+    int roff[MI][2];
     if (p.ridx != nullptr) {
       int gi[MI][2];                                      // gathered-row indices first, all in flight together
 #pragma unroll
@@ -355,13 +360,13 @@ __device__ __forceinline__ void prefetch_resid_rowmajor(const GemmParams& p, Res
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int m = m_base + mi * 16 + j * 8 + (lane >> 3);
-          roff[mi][j] = ((long)(m / p.r_np) * p.r_nsrc + gi[mi][j]) * p.ldr;
+          roff[mi][j] = ((m / p.r_np) * p.r_nsrc + gi[mi][j]) * (int)p.ldr;
         }
     } else {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) roff[mi][j] = (long)(m_base + mi * 16 + j * 8 + (lane >> 3)) * p.ldr;
+        for (int j = 0; j < 2; ++j) roff[mi][j] = (m_base + mi * 16 + j * 8 + (lane >> 3)) * (int)p.ldr;
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -402,22 +407,30 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
   constexpr int MAP = col_map(EPI, SF32);
   constexpr bool NAT = MAP == MAP_NAT;
   if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
-    if (!W8 && scratch != nullptr && pre.valid) {
+    if (scratch != nullptr && pre.valid) {
       // ROWMAJOR epilogue of an interior tile (see prefetch_resid_rowmajor): per row group and column half, the wave's 16 x 32
       // accumulator block goes through its 2 KiB LDS scratch - written in the MFMA layout (lane = row l15, columns 4 g..),
       // read back as 8 rows x 128 bytes per instruction (16-byte chunks XOR-swizzled by the row pair: conflict free both
       // ways) - meets the residual rows loaded in that shape, and leaves as whole 128-byte lines.
-      const int lane = g * 16 + l15;
+      int lane = g * 16 + l15;
+      asm volatile("" : "+v"(lane));                              // (not hoisted out of the tile loop: see prefetch_resid_rowmajor)
       const int rr = lane >> 3, cc = lane & 7;                    // read-back: row rr (+ 8 j), 16-byte chunk cc of the half
-      float bias[2][4], gam[2][4];
+      // column constants of the lane's 2 x 4 columns; fp8 weights: out = resid + gamma * (acc * ws + bias) = resid + (gamma
+      // * ws) * acc ... is NOT used - the product gamma * ws would round differently from the other tilings' (acc * ws) +
+      // bias, and sub-batches (128 x 128 tiling) must reproduce the full batch bit for bit
+      float bias[2][4], gam[2][4], wsc[2][W8 ? 4 : 1];
 #pragma unroll
-      for (int hc = 0; hc < 2; ++hc)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0w + 32 * hc + 4 * cc + e;
-          bias[hc][e] = p.bias != nullptr ? p.bias[n] : 0.f;
-          gam[hc][e] = p.gamma != nullptr ? p.gamma[n] : 1.f;
+      for (int hc = 0; hc < 2; ++hc) {
+        const int n = n0w + 32 * hc + 4 * cc;
+        const float4 bq = p.bias != nullptr ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gq = p.gamma != nullptr ? *reinterpret_cast<const float4*>(p.gamma + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        bias[hc][0] = bq.x; bias[hc][1] = bq.y; bias[hc][2] = bq.z; bias[hc][3] = bq.w;
+        gam[hc][0] = gq.x; gam[hc][1] = gq.y; gam[hc][2] = gq.z; gam[hc][3] = gq.w;
+        if constexpr (W8) {
+          const float4 wq = *reinterpret_cast<const float4*>(p.wscale + n);
+          wsc[hc][0] = wq.x; wsc[hc][1] = wq.y; wsc[hc][2] = wq.z; wsc[hc][3] = wq.w;
         }
+      }
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load so far has landed, on every path (see the note below)
       float* Y = reinterpret_cast<float*>(p.Y) + n0w + 4 * cc;
 #pragma unroll
@@ -437,10 +450,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
             const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
             const float4 r = pre.r[mi][2 * hc + j];
             float4 o;
-            o.x = fmaf(gam[hc][0], a[0] + bias[hc][0], r.x);
-            o.y = fmaf(gam[hc][1], a[1] + bias[hc][1], r.y);
-            o.z = fmaf(gam[hc][2], a[2] + bias[hc][2], r.z);
-            o.w = fmaf(gam[hc][3], a[3] + bias[hc][3], r.w);
+            o.x = fmaf(gam[hc][0], (W8 ? a[0] * wsc[hc][0] : a[0]) + bias[hc][0], r.x);
+            o.y = fmaf(gam[hc][1], (W8 ? a[1] * wsc[hc][1] : a[1]) + bias[hc][1], r.y);
+            o.z = fmaf(gam[hc][2], (W8 ? a[2] * wsc[hc][2] : a[2]) + bias[hc][2], r.z);
+            o.w = fmaf(gam[hc][3], (W8 ? a[3] * wsc[hc][3] : a[3]) + bias[hc][3], r.w);
             *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + row) * p.ldc + 32 * hc) = o;
           }
           __builtin_amdgcn_wave_barrier();   // the block's reads are issued before the next block's writes (LDS is in order per wave)
@@ -658,7 +671,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
   // fp32-stream RESID launches of the 256 x 128 tiling: full-line residual loads / output stores through a 2 KiB per-wave
   // LDS transpose behind the stages (host: RESID_SCRATCH_BYTES more dynamic LDS) - see prefetch_resid_rowmajor
   // (bf16 weights: with the fp8-weight scale on top the instantiation spills - it keeps the accumulator-layout epilogue)
-  constexpr bool ROWMAJOR = nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4 && !W8;
+  constexpr bool ROWMAJOR = nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4;
+  // (the 256 x 256 tiling's RESID instantiation - 128 accumulators, 246-249 VGPRs - spills 196-392 bytes with the same
+  //  epilogue, loads issued in the epilogue one row group ahead: it keeps the accumulator-layout epilogue)
 
   // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
   //      (fp8 W: a piece = 16 rows x 64 B, lane -> row lane>>2, 16-byte unit lane&3)
@@ -1252,11 +1267,13 @@ inline bool wide_wins_on_rounds(int M, int N, int cus) {
 // the 20 GEMM shapes of the schedule.
 inline int stream_grid(int total_tiles, int cus) { return total_tiles <= cus ? total_tiles : cus; }
 
-// Every other workgroup of an XCD starts a residual-epilogue launch 2 x 8192 cycles late, so that the two halves of the
-// chip do not hit their prologue loads and epilogue bursts in the same instant.  Measured (tools/stagger_probe.py,
-// tools/ab_forward.py stagger): proj alone -4 % at 1 unit and worse from 2 on, fc2 alone flat; in the forward 2 units
-// are best: 9.09 -> 9.03 ms (+0.5-0.8 %), 4 units neutral, 6 units -1.2 %.  rajni_debug_set_resid_stagger(0) turns it off.
-int g_resid_stagger = 2;
+// Every other workgroup of an XCD starts a residual-epilogue launch `units` x 8192 cycles late, so that the two halves of
+// the chip do not hit their prologue loads and epilogue bursts in the same instant.  Round 2 (tools/stagger_probe.py,
+// tools/ab_forward.py stagger): proj alone -4 % at 1 unit, fc2 alone flat; in the forward 2 units were best (+0.5-0.8 %).
+// Round 3, with the full-line epilogue: stand-alone proj now LOSES with any offset (84.4 us at 0, 88.5 at 1, 97.4 at 2 units;
+// four or eight phase groups worse still), in the forward 1 unit is best by 0.1-0.3 % (8.850 / 8.804 ms against 8.872 / 8.825
+// at 2 units and 8.878 / 8.838 at 0).  rajni_debug_set_resid_stagger(0) turns it off.
+int g_resid_stagger = 1;
 
 template <int EPI, int ALOAD, bool SF32, bool W8 = false>
 int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
@@ -1269,6 +1286,11 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if ((mode == 4 || mode == 5) && p.M < 256) mode = 1;   // stream tiles may start at M - 256
   if (mode == 4 && p.K < 192) mode = 1;                   // the persistent streams need >= NS + 1 K steps
   if (mode == 5 && p.K < 256) mode = 1;
+  // the 256 x 128 tiling's full-line residual epilogue addresses the residual tensor with 32-bit element offsets
+  constexpr bool RESID_NAT = nat_order(EPI, SF32) && EPI == EPI_RESID;
+  const long resid_rows = p.ridx != nullptr ? (long)(p.M / p.r_np) * p.r_nsrc : (long)p.M;
+  const bool mid_ok = !RESID_NAT || resid_rows * p.ldr < (1L << 31);
+  if (mode == 5 && !mid_ok) mode = 1;
   if (mode == 0) {
     // measured on ViT-B shapes (tools/gemm_bench.py, tools/proj_probe.py, profiles/):
     //   wide outputs (qkv, fc1): persistent 256x256 (950 / 870 TFLOP/s vs 750 / 700 for 128x128);
@@ -1276,7 +1298,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
     //   persistent 256x128 3-stage tiling is best (proj 125 us, fc2 284 us vs 127 / 310 for 128x128);
     //   small problems (head, tiny batches): 128x128.
     if (p.M >= 1024 && p.N >= 1536 && p.K >= 192) mode = 4;
-    else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N, cus)) ? 4 : 5;
+    else if (p.M >= 1024 && p.K >= 256) mode = (p.K > p.N && p.K >= 1536 && wide_wins_on_rounds(p.M, p.N, cus)) ? 4 : (mid_ok ? 5 : 1);
     else mode = 1;
   }
   static bool attr[5][RAJNI_MAX_DEVICES] = {};   // [0] small, [1] wide, [2] mid, [3] [4] their K<=N twins; per device
@@ -1289,23 +1311,24 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
-    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>, C::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
+    constexpr int lds = C::LDS_BYTES;
+    if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>, lds, attr[1])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
-      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, C::LDS_BYTES, attr[3])) != RAJNI_OK) return rc;
+      if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, lds, attr[3])) != RAJNI_OK) return rc;
     p.tiles_n = (p.N + 255) / 256;
     p.total_tiles = p.tiles_n * ((p.M + 255) / 256);
     p.nblk = n_block(p.tiles_n, (p.M + 255) / 256, 256, p.K, 2, cus);   // fp8 W: same blocks as bf16 (measured)
     const int grid = stream_grid(p.total_tiles, cus);
     if (EPI == EPI_RESID && kclass == KC_GEMM_RESID_SQ) {
       if constexpr (EPI == EPI_RESID)
-        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+        hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>), dim3(grid), dim3(512), lds, s, p);
     } else {
-      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>), dim3(grid), dim3(512), C::LDS_BYTES, s, p);
+      hipLaunchKernelGGL((wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>), dim3(grid), dim3(512), lds, s, p);
     }
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     // fp32-stream RESID: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 = 160 KiB)
-    constexpr int lds = C::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID && !W8) ? 8 * 2048 : 0);
+    constexpr int lds = C::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID) ? 8 * 2048 : 0);
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>, lds, attr[2])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
       if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, lds, attr[4])) != RAJNI_OK) return rc;
@@ -1368,14 +1391,16 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
                  (double)p.M * p.K + (ysz + rsz) * (double)p.M * p.N + (double)p.N * p.K);
   int rc;
   const int grid = stream_grid(p.total_tiles, cus);
+  // fp32-stream RESID: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 = 160 KiB)
+  constexpr int lds8 = f8::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID) ? 8 * 2048 : 0);
   if (EPI == EPI_RESID && tag_sq) {
     if constexpr (EPI == EPI_RESID) {
-      if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 1>, f8::LDS_BYTES, attr[1])) != RAJNI_OK) return rc;
-      hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 1>), dim3(grid), dim3(512), f8::LDS_BYTES, s, p);
+      if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 1>, lds8, attr[1])) != RAJNI_OK) return rc;
+      hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 1>), dim3(grid), dim3(512), lds8, s, p);
     }
   } else {
-    if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 0>, f8::LDS_BYTES, attr[0])) != RAJNI_OK) return rc;
-    hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 0>), dim3(grid), dim3(512), f8::LDS_BYTES, s, p);
+    if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 0>, lds8, attr[0])) != RAJNI_OK) return rc;
+    hipLaunchKernelGGL((f8::gemm_f8_tn_stream<EPI, SF32, 0>), dim3(grid), dim3(512), lds8, s, p);
   }
   RAJNI_CHECK_LAUNCH("gemm_f8_tn");
   return RAJNI_OK;
@@ -1386,6 +1411,7 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
 extern "C" void rajni_debug_force_gemm_tiling(int mode) { g_force_tiling = mode; }
 extern "C" void rajni_debug_force_f8_tiling(int mode) { g_force_f8_tiling = mode; }
 extern "C" void rajni_debug_set_resid_stagger(int units) { g_resid_stagger = units; }
+
 extern "C" void rajni_debug_set_gemm_nblock_bytes(int bytes) { g_nblk_bytes = bytes; }
 // diagnostic builds (-DRAJNI_GEMM_STAMPS): device buffer of 4 x u64 per workgroup, or NULL
 extern "C" void rajni_debug_set_gemm_stamps(void* buf) { rajni_g_stamps = (unsigned long long*)buf; }

@@ -291,26 +291,49 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
       // serialised load-wait-store)
       ResidPrefetch<MI> pre;
       pre.valid = false;
+      char* scratch = nullptr;
       if constexpr (nat_order(EPI, SF32) && EPI == EPI_RESID) {
         // loaded on EVERY path (addresses clamped into the tensor; edge tiles ignore the values): a conditional load
-        // leaves `pre` half-defined and hipcc then keeps its registers reserved around the whole tile loop
+        // leaves `pre` half-defined and hipcc then keeps its registers reserved around the whole tile loop.
+        // Round 3: in FULL 128-byte LINES - row group mi, instruction j: row 16 mi + 8 j + (lane >> 3), columns 4 (lane & 7)..
+        // of each 32-column half - the layout epilogue_tile's LDS transpose brings the accumulators to (one CU pulls 64-byte
+        // pieces at a third of the rate of whole lines: prefetch_resid_rowmajor in gemm.hip)
         const float* R = reinterpret_cast<const float*>(p.R);
+        const int cbase = n0w + 64 <= p.N ? n0w + 4 * (lane & 7) : 0;
+        if (p.ridx != nullptr) {
+          int gi[MI][2], mm[MI][2];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          int m = m_base + mi * 16 + l15;
-          if (m > p.M - 1) m = p.M - 1;
-          long rrow = m;
-          if (p.ridx != nullptr) rrow = (long)(m / p.r_np) * p.r_nsrc + p.ridx[m];
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            int c = n0w + 16 * ni + 4 * g;
-            if (c + 4 > p.N) c = 0;
-            pre.r[mi][ni] = *reinterpret_cast<const float4*>(R + rrow * p.ldr + c);
-          }
+            for (int j = 0; j < 2; ++j) {
+              int m = m_base + mi * 16 + j * 8 + (lane >> 3);
+              mm[mi][j] = m > p.M - 1 ? p.M - 1 : m;
+              gi[mi][j] = p.ridx[mm[mi][j]];
+            }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float* rp = R + ((long)(mm[mi][j] / p.r_np) * p.r_nsrc + gi[mi][j]) * p.ldr + cbase;
+              pre.r[mi][j] = *reinterpret_cast<const float4*>(rp);
+              pre.r[mi][2 + j] = *reinterpret_cast<const float4*>(rp + (n0w + 64 <= p.N ? 32 : 0));
+            }
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              int m = m_base + mi * 16 + j * 8 + (lane >> 3);
+              if (m > p.M - 1) m = p.M - 1;
+              const float* rp = R + (long)m * p.ldr + cbase;
+              pre.r[mi][j] = *reinterpret_cast<const float4*>(rp);
+              pre.r[mi][2 + j] = *reinterpret_cast<const float4*>(rp + (n0w + 64 <= p.N ? 32 : 0));
+            }
         }
         pre.valid = inter;
+        scratch = smem + LDS_BYTES + wave * 2048;     // host: 16 KiB more dynamic LDS for these instantiations
       }
-      epilogue_tile<EPI, SF32, MI, true>(p, acc, m_base, n0w, l15, g, pre, 0, inter);
+      epilogue_tile<EPI, SF32, MI, true>(p, acc, m_base, n0w, l15, g, pre, 0, inter, scratch);
     }
     __builtin_amdgcn_sched_barrier(0);    // keep the fragment reads below the epilogue (hoisted, they cost it 64 VGPRs)
 #ifdef RAJNI_GEMM_STAMPS
