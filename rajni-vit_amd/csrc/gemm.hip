@@ -495,9 +495,30 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
             v[j] = y[0]; v[j + 1] = y[1];
           }
         }
-        bf16_t* row = Y + (long)(m_base + mi * 16 + l15) * p.ldc;
-        store_u4<EPI == EPI_GELU>(row + ca, pack8(v));
-        store_u4<EPI == EPI_GELU>(row + cb, pack8(v + 8));
+        if (scratch != nullptr) {
+          // whole 128-byte lines: the wave's 16 x 64 bf16 block (one line per row) through its 2 KiB LDS scratch - written as
+          // the lane's two 16-byte pieces (chunks g and 4 + g of row l15), read back 8 rows x 128 bytes per instruction
+          // (same swizzle as the fp32-stream transpose above: conflict free both ways)
+          int lane = g * 16 + l15;
+          asm volatile("" : "+v"(lane));
+          const int rr = lane >> 3, cc = lane & 7;
+          const int key = (l15 >> 1) & 3;
+          *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + ((g ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(v));
+          *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + (((4 + g) ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(v + 8));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = 8 * j + rr;
+            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ ((row >> 1) & 3)) << 4)));
+            store_u4<EPI == EPI_GELU>(Y + (long)(m_base + mi * 16 + row) * p.ldc + n0w + 8 * cc, q);
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          bf16_t* row = Y + (long)(m_base + mi * 16 + l15) * p.ldc;
+          store_u4<EPI == EPI_GELU>(row + ca, pack8(v));
+          store_u4<EPI == EPI_GELU>(row + cb, pack8(v + 8));
+        }
       }
       return;
     }
@@ -615,6 +636,9 @@ struct XSource {
 // every LDS read and DMA issue sits between MFMAs (sched_group_barrier pins the order).
 // =============================================================================================
 #define RAJNI_GEMM_NBLK_BYTES (1600 * 1024)
+#ifndef RAJNI_TSTORE
+#define RAJNI_TSTORE 1
+#endif
 namespace wide {
 constexpr int BM = 256, BK = 64;
 constexpr int X_BYTES = BM * BK * 2;            // 32 KiB
@@ -672,6 +696,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
   // LDS transpose behind the stages (host: RESID_SCRATCH_BYTES more dynamic LDS) - see prefetch_resid_rowmajor
   // (bf16 weights: with the fp8-weight scale on top the instantiation spills - it keeps the accumulator-layout epilogue)
   constexpr bool ROWMAJOR = nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4;
+  constexpr bool TSTORE = RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU);   // bf16 outputs leave as whole lines too
   // (the 256 x 256 tiling's RESID instantiation - 128 accumulators, 246-249 VGPRs - spills 196-392 bytes with the same
   //  epilogue, loads issued in the epilogue one row group ahead: it keeps the accumulator-layout epilogue)
 
@@ -900,7 +925,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
 
     // ---- epilogue (the next tile's first loads are in flight)
     epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter,
-                                     ROWMAJOR ? smem + C::LDS_BYTES + wave * 2048 : nullptr);
+                                     (ROWMAJOR || TSTORE) ? smem + C::LDS_BYTES + wave * 2048 : nullptr);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1311,7 +1336,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
-    constexpr int lds = C::LDS_BYTES;
+    constexpr int lds = C::LDS_BYTES + ((RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU)) ? 8 * 2048 : 0);
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>, lds, attr[1])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
       if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, lds, attr[3])) != RAJNI_OK) return rc;
@@ -1328,7 +1353,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   } else if (mode == 5) {
     using C = wide::Cfg<2, 3, W8>;
     // fp32-stream RESID: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 = 160 KiB)
-    constexpr int lds = C::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID) ? 8 * 2048 : 0);
+    constexpr int lds = C::LDS_BYTES + (((nat_order(EPI, SF32) && EPI == EPI_RESID) || (RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU))) ? 8 * 2048 : 0);
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 0>, lds, attr[2])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
       if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 4, 2, 4, 3, W8, 1>, lds, attr[4])) != RAJNI_OK) return rc;
