@@ -130,6 +130,9 @@ __device__ __forceinline__ void store1(void* base, long off, float v) {
 // keeping the fp32 residual stream resident in the 256 MiB Infinity Cache by also moving the QKV output and FC2's X-operand
 // DMA past it - was negative: non-temporal X loads cost FC2 +15 % (its row panels are re-read by six column tiles out of L2),
 // non-temporal QKV stores cost attention +4 %; neither made the residual epilogues or LayerNorm faster.
+#ifndef RAJNI_FC1_NT
+#define RAJNI_FC1_NT 1
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ void store_u4(void* ptr, const uint4& v) {
@@ -511,13 +514,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           for (int j = 0; j < 2; ++j) {
             const int row = 8 * j + rr;
             const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ ((row >> 1) & 3)) << 4)));
-            store_u4<EPI == EPI_GELU>(Y + (long)(m_base + mi * 16 + row) * p.ldc + n0w + 8 * cc, q);
+            store_u4<RAJNI_FC1_NT && EPI == EPI_GELU>(Y + (long)(m_base + mi * 16 + row) * p.ldc + n0w + 8 * cc, q);
           }
           __builtin_amdgcn_wave_barrier();
         } else {
           bf16_t* row = Y + (long)(m_base + mi * 16 + l15) * p.ldc;
-          store_u4<EPI == EPI_GELU>(row + ca, pack8(v));
-          store_u4<EPI == EPI_GELU>(row + cb, pack8(v + 8));
+          store_u4<RAJNI_FC1_NT && EPI == EPI_GELU>(row + ca, pack8(v));
+          store_u4<RAJNI_FC1_NT && EPI == EPI_GELU>(row + cb, pack8(v + 8));
         }
       }
       return;
@@ -1416,8 +1419,8 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
                  (double)p.M * p.K + (ysz + rsz) * (double)p.M * p.N + (double)p.N * p.K);
   int rc;
   const int grid = stream_grid(p.total_tiles, cus);
-  // fp32-stream RESID: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 = 160 KiB)
-  constexpr int lds8 = f8::LDS_BYTES + ((nat_order(EPI, SF32) && EPI == EPI_RESID) ? 8 * 2048 : 0);
+  // fp32-stream RESID and bf16 outputs: 2 KiB of LDS per wave behind the three stages for the epilogue's transpose (144 + 16 KiB)
+  constexpr int lds8 = f8::LDS_BYTES + (((nat_order(EPI, SF32) && EPI == EPI_RESID) || EPI == EPI_BIAS) ? 8 * 2048 : 0);
   if (EPI == EPI_RESID && tag_sq) {
     if constexpr (EPI == EPI_RESID) {
       if ((rc = set_lds_attr(&f8::gemm_f8_tn_stream<EPI, SF32, 1>, lds8, attr[1])) != RAJNI_OK) return rc;

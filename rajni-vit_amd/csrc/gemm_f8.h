@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
       ResidPrefetch<MI> pre;
       pre.valid = false;
       char* scratch = nullptr;
+      if constexpr (EPI == EPI_BIAS) scratch = smem + LDS_BYTES + wave * 2048;   // bf16 output (QKV) as whole lines: epilogue_tile
       if constexpr (nat_order(EPI, SF32) && EPI == EPI_RESID) {
         // loaded on EVERY path (addresses clamped into the tensor; edge tiles ignore the values): a conditional load
         // leaves `pre` half-defined and hipcc then keeps its registers reserved around the whole tile loop.
