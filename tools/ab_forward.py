@@ -9,7 +9,7 @@ import rajni_amd
 from rajni_amd import timm_shaped as ts, _native as nat
 
 SWITCHES = {"nblock": (lambda v: nat.lib().rajni_debug_set_gemm_nblock_bytes(v), [0, 1600 * 1024]),
-            "stagger": (lambda v: nat.lib().rajni_debug_set_resid_stagger(v), [2, 0, 1])}
+            "stagger": (lambda v: nat.lib().rajni_debug_set_resid_stagger(v), [1, 0, 2])}
 name = sys.argv[1] if len(sys.argv) > 1 else "nblock"
 model_name = sys.argv[2] if len(sys.argv) > 2 else "vit_base_patch16_224"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256

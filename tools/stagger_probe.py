@@ -8,9 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "rajni-vit_amd"))
 import torch
 from rajni_amd import ops, _native as nat
 dev = "cuda"
-import ctypes
-nat.lib().rajni_debug_set_resid_stagger_groups.argtypes = [ctypes.c_int]
-units = [(2, 0), (2, 1), (2, 2), (2, 3), (2, 4), (4, 1), (4, 2), (4, 3), (8, 1), (8, 2)]     # (phase groups, units of 8k cycles per group step)
+units = [0, 1, 2, 3, 4, 6, 8]
 for name, M, N, K in [("proj_197", 50432, 768, 768), ("proj_152", 38912, 768, 768), ("fc2_197", 50432, 768, 3072),
                       ("fc2_152", 38912, 768, 3072), ("fc2_87", 22272, 768, 3072)]:
     x = torch.randn(1, M, K, device=dev).to(torch.bfloat16)
@@ -20,12 +18,12 @@ for name, M, N, K in [("proj_197", 50432, 768, 768), ("proj_152", 38912, 768, 76
     best = {u: 1e9 for u in units}
     for r in range(6):
         for u in units:
-            nat.lib().rajni_debug_set_resid_stagger_groups(u[0]); nat.lib().rajni_debug_set_resid_stagger(u[1])
+            nat.lib().rajni_debug_set_resid_stagger(u)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
                 ops.linear(x, w, N, b, nat.EPI_BIAS_RESID, resid=resid, out=resid.view(M, N))
             e1.record(); torch.cuda.synchronize()
             if r: best[u] = min(best[u], e0.elapsed_time(e1) / 5 * 1e3)
-    nat.lib().rajni_debug_set_resid_stagger_groups(2); nat.lib().rajni_debug_set_resid_stagger(2)
-    print(name, "  ".join(f"{u[0]}g x{u[1]}: {t:.1f}" for u, t in best.items()), flush=True)
+    nat.lib().rajni_debug_set_resid_stagger(1)
+    print(name, "  ".join(f"{u}: {t:.1f}us" for u, t in best.items()), flush=True)
