@@ -464,6 +464,61 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
       return;
     }
   }
+  if constexpr (NAT && EPI == EPI_RESID && MI > 4 && !W8) {
+    // the 256 x 256 tiling (fc2 where its tile count fills the rounds better; in place, no gathered rows): the same full-line
+    // epilogue, one 16-row group at a time with its residual rows loaded right here (128 accumulators leave no registers
+    // to prefetch them under the last K step or to run a group ahead: both forms spilled 196-392 bytes)
+    if (scratch != nullptr && interior && p.ridx == nullptr) {
+      int lane = g * 16 + l15;
+      asm volatile("" : "+v"(lane));
+      const int rr = lane >> 3, cc = lane & 7;
+      float bias[2][4], gam[2][4];
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc) {
+        const int n = n0w + 32 * hc + 4 * cc;
+        const float4 bq = p.bias != nullptr ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gq = p.gamma != nullptr ? *reinterpret_cast<const float4*>(p.gamma + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        bias[hc][0] = bq.x; bias[hc][1] = bq.y; bias[hc][2] = bq.z; bias[hc][3] = bq.w;
+        gam[hc][0] = gq.x; gam[hc][1] = gq.y; gam[hc][2] = gq.z; gam[hc][3] = gq.w;
+      }
+      const float* R = reinterpret_cast<const float*>(p.R) + n0w + 4 * cc;
+      float* Y = reinterpret_cast<float*>(p.Y) + n0w + 4 * cc;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        float4 r[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const long ro = (long)(m_base + mi * 16 + 8 * j + rr) * p.ldr;
+          r[j] = *reinterpret_cast<const float4*>(R + ro);
+          r[2 + j] = *reinterpret_cast<const float4*>(R + ro + 32);
+        }
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int slot = (4 * q + g) ^ ((l15 >> 1) & 3);
+            *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + slot * 16) = __builtin_bit_cast(bf16x8, acc[2 * hc + q][mi]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = 8 * j + rr, slot = cc ^ ((row >> 1) & 3);
+            const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
+            float4 o;
+            o.x = fmaf(gam[hc][0], a[0] + bias[hc][0], r[2 * hc + j].x);
+            o.y = fmaf(gam[hc][1], a[1] + bias[hc][1], r[2 * hc + j].y);
+            o.z = fmaf(gam[hc][2], a[2] + bias[hc][2], r[2 * hc + j].z);
+            o.w = fmaf(gam[hc][3], a[3] + bias[hc][3], r[2 * hc + j].w);
+            *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + row) * p.ldc + 32 * hc) = o;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on every path (see the note below)
+      return;
+    }
+  }
   if constexpr (MAP == MAP_SEC && (EPI == EPI_BIAS || EPI == EPI_GELU)) {
     // interior tile of a bf16-output launch (QKV, FC1 - the bulk of all tiles): no row or column guard, the
     // lane's 2 x 8 columns of bias (and fp8 scale) as four 16-byte loads, two 16-byte stores per row.  The
@@ -700,8 +755,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
   // (bf16 weights: with the fp8-weight scale on top the instantiation spills - it keeps the accumulator-layout epilogue)
   constexpr bool ROWMAJOR = nat_order(EPI, SF32) && EPI == EPI_RESID && MI <= 4;
   constexpr bool TSTORE = RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU);   // bf16 outputs leave as whole lines too
-  // (the 256 x 256 tiling's RESID instantiation - 128 accumulators, 246-249 VGPRs - spills 196-392 bytes with the same
-  //  epilogue, loads issued in the epilogue one row group ahead: it keeps the accumulator-layout epilogue)
+  constexpr bool ROWMAJOR_WIDE = nat_order(EPI, SF32) && EPI == EPI_RESID && MI > 4 && !W8;    // loads in the epilogue, group by group
 
   // ---- staging: a piece = 1 KiB = 8 rows x 128 B; wave w stages X pieces 4w..4w+3, W pieces PW*w..
   //      (fp8 W: a piece = 16 rows x 64 B, lane -> row lane>>2, 16-byte unit lane&3)
@@ -928,7 +982,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_bf16_tn_stream(const Gem
 
     // ---- epilogue (the next tile's first loads are in flight)
     epilogue_tile<EPI, SF32, MI, W8>(p, acc, m0 + wm * (MI * 16), n0 + wn * 64, l15, g, pre, m_lo, inter,
-                                     (ROWMAJOR || TSTORE) ? smem + C::LDS_BYTES + wave * 2048 : nullptr);
+                                     (ROWMAJOR || ROWMAJOR_WIDE || TSTORE) ? smem + C::LDS_BYTES + wave * 2048 : nullptr);
 #ifdef RAJNI_GEMM_STAMPS
     if (p.stamps != nullptr && wave == 0) {
       const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1339,7 +1393,7 @@ int launch_gemm(GemmParams p, int kclass, hipStream_t s) {
   if (mode == 4) {
     using C = wide::Cfg<4, RAJNI_W8_WIDE_NS_OR(W8), W8>;
     constexpr int NS = RAJNI_W8_WIDE_NS_OR(W8);
-    constexpr int lds = C::LDS_BYTES + ((RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU)) ? 8 * 2048 : 0);
+    constexpr int lds = C::LDS_BYTES + (((RAJNI_TSTORE && (EPI == EPI_BIAS || EPI == EPI_GELU)) || (nat_order(EPI, SF32) && EPI == EPI_RESID && !W8)) ? 8 * 2048 : 0);
     if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 0>, lds, attr[1])) != RAJNI_OK) return rc;
     if constexpr (EPI == EPI_RESID)
       if ((rc = set_lds_attr(&wide::gemm_bf16_tn_stream<EPI, ALOAD, SF32, 2, 4, 8, NS, W8, 1>, lds, attr[3])) != RAJNI_OK) return rc;
