@@ -453,10 +453,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
             const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
             const float4 r = pre.r[mi][2 * hc + j];
             float4 o;
-            o.x = fmaf(gam[hc][0], (W8 ? a[0] * wsc[hc][0] : a[0]) + bias[hc][0], r.x);
-            o.y = fmaf(gam[hc][1], (W8 ? a[1] * wsc[hc][1] : a[1]) + bias[hc][1], r.y);
-            o.z = fmaf(gam[hc][2], (W8 ? a[2] * wsc[hc][2] : a[2]) + bias[hc][2], r.z);
-            o.w = fmaf(gam[hc][3], (W8 ? a[3] * wsc[hc][3] : a[3]) + bias[hc][3], r.w);
+            o.x = fmaf(gam[hc][0], W8 ? fmaf(a[0], wsc[hc][0], bias[hc][0]) : a[0] + bias[hc][0], r.x);
+            o.y = fmaf(gam[hc][1], W8 ? fmaf(a[1], wsc[hc][1], bias[hc][1]) : a[1] + bias[hc][1], r.y);
+            o.z = fmaf(gam[hc][2], W8 ? fmaf(a[2], wsc[hc][2], bias[hc][2]) : a[2] + bias[hc][2], r.z);
+            o.w = fmaf(gam[hc][3], W8 ? fmaf(a[3], wsc[hc][3], bias[hc][3]) : a[3] + bias[hc][3], r.w);
             *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + row) * p.ldc + 32 * hc) = o;
           }
           __builtin_amdgcn_wave_barrier();   // the block's reads are issued before the next block's writes (LDS is in order per wave)
@@ -603,12 +603,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
   // DMA queue in every K step (measured: -15 % on the 3-stage tiling).  It costs nothing here: the uses
   // below need the same wait, and vector-memory ops retire in order.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  if constexpr (W8) {   // dequantise: accumulator column n times the scale of W row n
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[j >> 2][mi][j & 3] *= wsc[j];
-  }
+  // W8 dequantises inside the bias add - ONE fused multiply-add fmaf(acc, scale of W row n, bias), the same expression on every
+  // epilogue path of every tiling, so that which tiling served a launch never shows in the result
+  auto sb = [&](float a, int j) { return W8 ? fmaf(a, wsc[W8 ? j : 0], bias[j]) : a + bias[j]; };
   if constexpr (NAT && EPI == EPI_RESID && MI <= 4) {
     if (pre.valid) {   // interior tile whose residual rows were prefetched during the last K step
       float* Y = reinterpret_cast<float*>(p.Y);
@@ -617,10 +614,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           float4 o;
-          o.x = fmaf(gam[4 * ni + 0], acc[ni][mi][0] + bias[4 * ni + 0], pre.r[mi][ni].x);
-          o.y = fmaf(gam[4 * ni + 1], acc[ni][mi][1] + bias[4 * ni + 1], pre.r[mi][ni].y);
-          o.z = fmaf(gam[4 * ni + 2], acc[ni][mi][2] + bias[4 * ni + 2], pre.r[mi][ni].z);
-          o.w = fmaf(gam[4 * ni + 3], acc[ni][mi][3] + bias[4 * ni + 3], pre.r[mi][ni].w);
+          o.x = fmaf(gam[4 * ni + 0], sb(acc[ni][mi][0], 4 * ni + 0), pre.r[mi][ni].x);
+          o.y = fmaf(gam[4 * ni + 1], sb(acc[ni][mi][1], 4 * ni + 1), pre.r[mi][ni].y);
+          o.z = fmaf(gam[4 * ni + 2], sb(acc[ni][mi][2], 4 * ni + 2), pre.r[mi][ni].z);
+          o.w = fmaf(gam[4 * ni + 3], sb(acc[ni][mi][3], 4 * ni + 3), pre.r[mi][ni].w);
           *reinterpret_cast<float4*>(Y + (long)(m_base + mi * 16 + l15) * p.ldc + n0w + 16 * ni + 4 * g) = o;
         }
       }
@@ -635,7 +632,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = acc[ni][mi][rg] + bias[ni * 4 + rg];
+      for (int rg = 0; rg < 4; ++rg) v[ni * 4 + rg] = sb(acc[ni][mi][rg], ni * 4 + rg);
     if (NAT) epilogue_row_nat<EPI>(p, m, n0w, g, v, gam);
     else epilogue_row<EPI, SF32>(p, m, n0w + 8 * g, n0w + 32 + 8 * g, v, gam);
   }
