@@ -1441,9 +1441,18 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
   if constexpr (EPI == EPI_BIAS || EPI == EPI_GELU8) {
     const bool wide_ok = p.K >= 384;
     // measured on ViT-B at batch 256 (K = 768: 6 K steps per tile, so per-tile costs weigh double against the bf16
-    // tilings): FC1 + GELU -> e4m3 132 us on 256 x 256 vs 139 us on 256 x 128; QKV -> bf16 117 vs 105 us (its 128 KB
-    // of bf16 output per tile leave as half sectors: only 2 lanes of a 32 x 32 accumulator share a row)
-    const bool want = g_force_f8_tiling == 2 || (g_force_f8_tiling == 0 && EPI == EPI_GELU8 && p.M >= 1024 && p.N >= 1536);
+    // tilings): FC1 + GELU -> e4m3 132 us on 256 x 256 vs 139 us on 256 x 128.  QKV -> bf16: 256 x 256 since its
+    // epilogue stores whole lines (tools/f8_qkv_tiling.py, us at 197 / 173 / 152 / 121 / 87 tokens: 120.5 / 118.8 / 93.7 /
+    // 74.3 / 61.6 against 128.1 / 102.0 / 103.4 / 78.6 / 60.8 on 256 x 128; batch 512: 264.5 / 234.4 / 205.6 / 150.0 /
+    // 112.3 against 288.3 / 251.6 / 220.1 / 155.8 / 100.4) - except where its tiles end just past a whole number of
+    // rounds in a short launch (6.08 and 6.12 rounds above: the nearly empty last round costs 12-16 %)
+    auto rounds_ok = [&]() {
+      const double rounds = (double)((p.M + 255) / 256) * ((p.N + f8w::BN - 1) / f8w::BN) / cus;
+      const double frac = rounds - (long)rounds;
+      return !(rounds < 8.0 && frac > 0.0 && frac < 0.2);
+    };
+    const bool want = g_force_f8_tiling == 2 ||
+                      (g_force_f8_tiling == 0 && p.M >= 1024 && p.N >= 1536 && (EPI == EPI_GELU8 || (RAJNI_F8W_LINES && rounds_ok())));
     if (wide_ok && want) {
       p.tiles_n = (p.N + f8w::BN - 1) / f8w::BN;
       const int tiles_m = (p.M + 255) / 256;
@@ -1453,8 +1462,10 @@ int launch_gemm_f8(GemmParams p, int kclass, bool tag_sq, hipStream_t s) {
       ProfScope prof(kclass, s, 2.0 * p.M * (double)p.N * p.K,
                      (double)p.M * p.K + (EPI == EPI_GELU8 ? 1.0 : 2.0) * (double)p.M * p.N + (double)p.N * p.K);
       int rc;
-      if ((rc = set_lds_attr(&f8w::gemm_f8_tn_wide<EPI>, f8w::LDS_BYTES, attrw)) != RAJNI_OK) return rc;
-      hipLaunchKernelGGL((f8w::gemm_f8_tn_wide<EPI>), dim3(stream_grid(p.total_tiles, cus)), dim3(512), f8w::LDS_BYTES, s, p);
+      // bf16 output: 4 KiB of LDS per wave behind the two stages for the epilogue's whole-line transpose (128 + 32 = 160 KiB)
+      constexpr int ldsw = f8w::LDS_BYTES + ((EPI == EPI_BIAS && RAJNI_F8W_LINES) ? 8 * 4096 : 0);
+      if ((rc = set_lds_attr(&f8w::gemm_f8_tn_wide<EPI>, ldsw, attrw)) != RAJNI_OK) return rc;
+      hipLaunchKernelGGL((f8w::gemm_f8_tn_wide<EPI>), dim3(stream_grid(p.total_tiles, cus)), dim3(512), ldsw, s, p);
       RAJNI_CHECK_LAUNCH("gemm_f8_tn_wide");
       return RAJNI_OK;
     }

@@ -376,6 +376,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
 //   half 2: 8 MFMAs(j, ks1)  ||  12 LDS reads of (j+1, ks0)  ||  8 DMA pieces of step j+2 into stage j
 // Epilogues: bias -> bf16 (QKV) and bias + GELU -> e4m3 (FC1).  Host contract: K % 128 == 0, K >= 384.
 // =============================================================================================
+#ifndef RAJNI_F8W_LINES
+#define RAJNI_F8W_LINES 1
+#endif
 namespace f8w {
 using f8::Frag;
 using f8::frag_bits;
@@ -577,6 +580,57 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
         inv[mi] = 1.0f / p.yscale[m < p.M ? m : p.M - 1];
       }
     }
+    bool lines_done = false;
+    if constexpr (EPI == EPI_BIAS && RAJNI_F8W_LINES) {
+      if (inter) {
+        // interior tile, bf16 output as whole 128-byte lines: per 32-row group the wave's 32 x 64 block (two 16-byte pieces
+        // per lane and column tile: chunks 4 ni + 2 h, + 1 of row r) goes through 4 KiB of LDS behind the stages - slot =
+        // chunk ^ ((row >> 1) & 7), conflict free both ways - and leaves as 8 rows x 128 bytes per instruction.  Stored
+        // straight from the accumulator layout an instruction touches 32 rows x 64 bytes (two lanes per row): half lines,
+        // which a CU moves at a third of the rate (tools/pull_probe.hip) - the reason QKV used the 256 x 128 kernel.
+        char* scratch = smem + LDS_BYTES + wave * 4096;
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int rr = lane_v >> 3, cc = lane_v & 7;
+        float bs[NT][16], ws[NT][16];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int c0 = n0w + 32 * ni + 16 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 wq = *reinterpret_cast<const float4*>(p.wscale + c0 + 4 * q);
+            const float4 bq = p.bias != nullptr ? *reinterpret_cast<const float4*>(p.bias + c0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ws[ni][4 * q] = wq.x; ws[ni][4 * q + 1] = wq.y; ws[ni][4 * q + 2] = wq.z; ws[ni][4 * q + 3] = wq.w;
+            bs[ni][4 * q] = bq.x; bs[ni][4 * q + 1] = bq.y; bs[ni][4 * q + 2] = bq.z; bs[ni][4 * q + 3] = bq.w;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on every path: see epilogue_tile
+        bf16_t* Y = reinterpret_cast<bf16_t*>(p.Y) + n0w + 8 * cc;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int key = (r >> 1) & 7;
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) {
+            float y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = fmaf(acc[ni][mi][j] * xsr[mi], ws[ni][j], bs[ni][j]);
+            *reinterpret_cast<bf16x8*>(scratch + r * 128 + (((4 * ni + 2 * h) ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(y));
+            *reinterpret_cast<bf16x8*>(scratch + r * 128 + (((4 * ni + 2 * h + 1) ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(y + 8));
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 8 * j + rr;
+            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)));
+            *reinterpret_cast<uint4*>(Y + (long)(m_base + mi * 32 + row) * p.ldc) = q;
+          }
+          __builtin_amdgcn_wave_barrier();   // the group's reads are issued before the next group's writes
+        }
+        lines_done = true;
+      }
+    }
+    if (!lines_done)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int c0 = n0w + 32 * ni + 16 * h;       // this lane's 16 consecutive columns of the tile

@@ -9,6 +9,7 @@ import rajni_amd
 from rajni_amd import timm_shaped as ts, _native as nat
 
 SWITCHES = {"nblock": (lambda v: nat.lib().rajni_debug_set_gemm_nblock_bytes(v), [0, 1600 * 1024]),
+            "nblockscan": (lambda v: nat.lib().rajni_debug_set_gemm_nblock_bytes(v), [1600 * 1024, 800 * 1024, 1200 * 1024, 2400 * 1024, 3200 * 1024]),
             "stagger": (lambda v: nat.lib().rajni_debug_set_resid_stagger(v), [1, 0, 2])}
 name = sys.argv[1] if len(sys.argv) > 1 else "nblock"
 model_name = sys.argv[2] if len(sys.argv) > 2 else "vit_base_patch16_224"
@@ -29,6 +30,6 @@ for r in range(5):
         for _ in range(10):
             m(x)
         torch.cuda.synchronize(); res[v].append((time.perf_counter() - t0) / 10 * 1e3)
-setter(values[-1])
+setter(values[0] if name == 'nblockscan' else values[-1])
 for v in values:
     print(f"{name}={v}: min {min(res[v]):.3f} ms  median {sorted(res[v])[len(res[v]) // 2]:.3f} ms  -> {B / min(res[v]) * 1e3:.0f} img/s")
