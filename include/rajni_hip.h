@@ -46,7 +46,7 @@ enum {
                               model.py:59 (mlp.fc2, ls2, add)                                       */
 };
 
-#define RAJNI_ABI_VERSION 7 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
+#define RAJNI_ABI_VERSION 8 /* bumped whenever a struct or an entry point changes; checked by the ctypes binding */
 int rajni_abi_version(void); /* == RAJNI_ABI_VERSION of the header the library was built from */
 const char* rajni_last_error(void);
 /* 0 when a gfx950 device is usable by this process, else an error code (message in last_error) */
@@ -83,6 +83,19 @@ int rajni_gather_rows(const void* src, const int32_t* idx, void* dst, int B, int
  * kernels; other head dims take a general MFMA kernel). */
 int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                     int H, int D, float scale, int dtype, rajni_stream_t stream);
+/* The same attention (bf16 qkv) with its output rows quantised for an fp8 x fp8 proj (opt-in "fp8_mfma" format; the
+ * reference has no fp8 semantics - this is the build's rule):
+ *   out_q[b,q,c] = e4m3_rne_sat(attn[b,q,c] * (1 / out_scale))  as bytes [B,np,H*D];  row_scale[b*np + q] = out_scale
+ * (the per-row dequantisation scales the proj launch takes as rajni_linear_args.x_scale).  ONE scale per launch: an
+ * attention row spans H (image, head) work items, so no item can know the row's maximum; the caller passes a bound -
+ * attention output is a convex combination of V rows, |V[j,c]| <= ||ln1(x)[j]||_2 ||Wv[c]||_2 + |bv[c]| and
+ * ||ln1(x)[j]||_2 <= sqrt(C) max|gamma1| + ||beta1||_2 (a normalised row has norm <= sqrt(C)), so
+ *   out_scale = (1.0625 * (sqrt(C) * max|gamma1| + ||beta1||_2) * max_c ||Wv[c]||_2 + max|bv|) / 448
+ * (the 1.0625 covers the e4m3 rounding of the LayerNorm rows; the conversion saturates).  e4m3 is a floating-point
+ * format: a bound a few binades above the true maximum costs range at the bottom, not precision.
+ * Head dim 64 and np <= 224 only (RAJNI_ERR_UNSUPPORTED otherwise). */
+int rajni_attention_fp8(const void* qkv, const int32_t* keep_idx, void* out_q, float out_scale, float* row_scale,
+                        int B, int n_src, int np, int H, int D, float scale, rajni_stream_t stream);
 
 /* ---- LayerNorm over the last axis (blk.norm1 / norm2 / m.norm)            model.py:51,59,65 ----
  * x rows are `x_row_stride` elements apart (lets the final norm read CLS rows only), y is dense
@@ -169,6 +182,10 @@ typedef struct {
   /* act_fp8 plans only: max_n ||W1deq[n,:]||_2 and max_n |b1[n]| of this block's fc1 (the hidden-activation
    * bound of rajni_layernorm_fp8) */
   float fc1_rownorm_max, fc1_bias_absmax;
+  /* act_fp8 plans only: out_scale of rajni_attention_fp8 for this block (> 0: where the block's attention launch has
+   * head dim 64 and at most 224 tokens, the attention output is emitted as e4m3 rows and proj runs on the fp8 matrix
+   * pipe; 0: proj keeps bf16 activations x e4m3 weights) */
+  float attn_out_scale;
 } rajni_block;
 
 typedef struct {
@@ -196,8 +213,10 @@ typedef struct {
   int act_fp8;                                 /* 1 (opt-in, needs e4m3 block weights): norm1 / norm2 emit per-row
                                                   scaled e4m3 activations, QKV / FC1 / FC2 run on the fp8 matrix
                                                   pipe, FC1's GELU epilogue re-quantises the hidden activations
-                                                  (rajni_layernorm_fp8, rajni_linear_args.x_scale).  Attention, proj,
-                                                  patch embed, head and the residual stream are unchanged.
+                                                  (rajni_layernorm_fp8, rajni_linear_args.x_scale); blocks with attn_out_scale > 0
+                                                  also emit the attention output as e4m3 rows and run proj on that pipe
+                                                  (rajni_attention_fp8).  Attention's products, patch embed, head and the
+                                                  residual stream are unchanged.
                                                   C % 256 == 0 and hidden % 256 == 0.  0 (default): bf16 activations */
 } rajni_vit_plan;
 
@@ -208,7 +227,7 @@ int rajni_vit_forward(const rajni_vit_plan* plan, const void* images, void* logi
 
 /* ---- measurement hooks (bench.py roofline): HIP-event timing per kernel class on the launch
  * stream.  mask bit i enables class i; classes listed by rajni_profile_class_name(). ---- */
-enum { RAJNI_NUM_KCLASS = 16 };
+enum { RAJNI_NUM_KCLASS = 17 };
 void rajni_profile_enable(unsigned mask);
 const char* rajni_profile_class_name(int kclass);
 /* synchronises the recorded events, ADDS them into the accumulators, returns them: per class the

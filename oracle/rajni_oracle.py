@@ -176,10 +176,13 @@ def gather_rows(x: np.ndarray, idx: np.ndarray) -> np.ndarray:
 def rajni_attention(x_norm: np.ndarray, sd: Dict[str, np.ndarray], prefix: str, num_heads: int,
                     keep_ratio: float, update: bool = True,
                     prev_scores: Optional[np.ndarray] = None,
-                    forced_keep_idx: Optional[np.ndarray] = None, dtype=np.float64):
+                    forced_keep_idx: Optional[np.ndarray] = None, dtype=np.float64,
+                    fp8_out_scale: Optional[float] = None):
     """returns (out [B,Np,C], keep_idx [B,Np] int64, next_scores [B,Np], scores [B,N]).
 
     `forced_keep_idx` replaces the selection (selection-conditional parity).
+    `fp8_out_scale`: the build's opt-in fp8 format - the attention output passes through e4m3 with this one scale before
+    proj (rajni_attention_fp8) where the launch qualifies (attention_out_is_fp8).
     """
     x_norm = np.asarray(x_norm, dtype=dtype)
     B, N, C = x_norm.shape
@@ -196,6 +199,8 @@ def rajni_attention(x_norm: np.ndarray, sd: Dict[str, np.ndarray], prefix: str, 
     q, k, v = split_heads(qkv, num_heads)                              # attention.py:46-49
     D = C // num_heads
     out = softmax_attention(q, k, v, D ** -0.5)                        # attention.py:51-54
+    if fp8_out_scale is not None and attention_out_is_fp8(D, out.shape[1]):
+        out = quantize_rows_e4m3(out, np.float32(fp8_out_scale)).astype(dtype)
     out = linear(out, W("proj.weight"), W("proj.bias"))                # attention.py:55-56
     next_scores = np.take_along_axis(scores, keep_idx, axis=1)         # attention.py:58
     return out, keep_idx, next_scores, scores
@@ -261,6 +266,26 @@ def hidden_scale_bound(xn: np.ndarray, fc1_w: np.ndarray, fc1_b: np.ndarray) -> 
     return np.where(bound > 0, bound / np.float32(448.0), np.float32(1.0)).astype(np.float32)
 
 
+def attention_out_is_fp8(head_dim: int, n_tokens: int) -> bool:
+    """where an act_fp8 plan emits e4m3 attention rows: the launches the persistent head-dim-64 kernel serves
+    (rajni_attention_fp8: D == 64, at most 224 kept tokens); elsewhere proj keeps bf16 activations"""
+    return head_dim == 64 and n_tokens <= 224
+
+
+def attention_out_scale(norm1_w: np.ndarray, norm1_b: np.ndarray, wv: np.ndarray, bv: Optional[np.ndarray]) -> np.float32:
+    """The one scale of a block's e4m3 attention output (include/rajni_hip.h, rajni_attention_fp8): attention rows are convex
+    combinations of V rows, |V[j,c]| <= ||ln1(x)[j]||_2 ||Wv[c]||_2 + |bv[c]|, ||ln1(x)[j]||_2 <= sqrt(C) max|gamma1| +
+    ||beta1||_2;  (1.0625 * that * max_c ||Wv[c]||_2 + max|bv|) / 448 in fp32."""
+    g, b = np.asarray(norm1_w, dtype=np.float32), np.asarray(norm1_b, dtype=np.float32)
+    wv = np.asarray(wv, dtype=np.float32)
+    wn = np.float32(np.sqrt((wv.astype(np.float64) ** 2).sum(axis=1)).max())
+    ln = np.float32(np.sqrt(np.float32(wv.shape[1]))) * np.float32(np.abs(g).max()) + np.float32(np.sqrt((b.astype(np.float64) ** 2).sum()))
+    bound = np.float32(1.0625) * ln * wn
+    if bv is not None:
+        bound = bound + np.float32(np.abs(np.asarray(bv, dtype=np.float32)).max())
+    return np.float32(bound / np.float32(448.0))
+
+
 def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, depth: int,
                 num_heads: int, ln_eps: float = 1e-6,
                 forced_keep: Optional[Dict[int, np.ndarray]] = None, dtype=np.float64,
@@ -272,7 +297,8 @@ def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, dept
     A pos_embed with N-1 rows (timm `no_embed_class`) is added to the patch tokens only - the
     mathematically identical fix for SURVEY B3.
     `act_fp8`: the build's opt-in fp8 activations - norm1 / norm2 outputs and the MLP hidden activations pass
-    through per-row e4m3 quantisation (see quantize_rows_e4m3) before qkv / fc1 / fc2.
+    through per-row e4m3 quantisation (see quantize_rows_e4m3) before qkv / fc1 / fc2, and the attention output through
+    e4m3 with one scale per block (attention_out_scale) before proj where attention_out_is_fp8.
     """
     schedule = normalise_schedule(schedule)
     P = lambda n: np.asarray(sd[n], dtype=dtype)
@@ -295,19 +321,25 @@ def vit_forward(sd: Dict[str, np.ndarray], images: np.ndarray, schedule, *, dept
         ls1 = P(p + "ls1.gamma") if (p + "ls1.gamma") in sd else None  # model.py:45-48
         ls2 = P(p + "ls2.gamma") if (p + "ls2.gamma") in sd else None
         xn = layer_norm(x, P(p + "norm1.weight"), P(p + "norm1.bias"), ln_eps)
+        osc = None
         if act_fp8:
             xn = quantize_rows_e4m3(xn, row_scale_e4m3(xn)).astype(dtype)
+            Cc = x.shape[-1]
+            osc = attention_out_scale(sd[p + "norm1.weight"], sd[p + "norm1.bias"], sd[p + "attn.qkv.weight"][2 * Cc:3 * Cc],
+                                      sd[p + "attn.qkv.bias"][2 * Cc:3 * Cc] if (p + "attn.qkv.bias") in sd else None)
         if i in schedule:                                              # model.py:50-59
             cfg = schedule[i]
             out, keep_idx, scores, full = rajni_attention(
                 xn, sd, p + "attn.", num_heads, cfg["keep_ratio"], cfg["update"], scores,
-                None if forced_keep is None else forced_keep.get(i), dtype=dtype)
+                None if forced_keep is None else forced_keep.get(i), dtype=dtype, fp8_out_scale=osc)
             trace[i] = {"scores": full, "keep_idx": keep_idx, "next_scores": scores}
             x = gather_rows(x, keep_idx)                               # model.py:55-56
         else:                                                          # model.py:61-63 (timm Block)
             qkv = linear(xn, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"))
             q, k, v = split_heads(qkv, num_heads)
             out = softmax_attention(q, k, v, (x.shape[-1] // num_heads) ** -0.5)
+            if osc is not None and attention_out_is_fp8(x.shape[-1] // num_heads, out.shape[1]):
+                out = quantize_rows_e4m3(out, osc).astype(dtype)
             out = linear(out, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"))
             scores = None
         x = x + (out if ls1 is None else out * ls1)                    # model.py:58

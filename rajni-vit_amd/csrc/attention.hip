@@ -30,7 +30,19 @@ struct AttnArgs {
   int n_src, np, H;
   float c;          // scale * log2(e)
   unsigned long long* stamps;   // diagnostic builds (-DRAJNI_ATTN_STAMPS) only
+  // fp8 output (rajni_attention_fp8; the O8 instantiations): rows as e4m3_rne_sat(o * oinv) bytes [B,np,H*64], and the
+  // dequantisation scale 1 / oinv written to row_scale[b*np + q] (by the head-0 items) for the fp8 proj launch
+  unsigned char* out8;
+  float oinv, oscale;
+  float* row_scale;
 };
+__device__ __forceinline__ unsigned attn_pack4_e4m3(float a, float b, float c, float d) {   // saturating RNE (gemm_f8.h)
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
 
 __device__ __forceinline__ int k_off(int row, int chunk) {   // K tile: natural row reads
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -220,7 +232,7 @@ constexpr bool stage_o(int nsub) { return (RAJNI_ATTN_STAGE_MASK >> (nsub - 1)) 
 // layout a lane owns 8 bytes of 8 different rows per instruction: 32 partial cache lines each, which backed
 // up the vector-memory queue - the NEXT item's prefetch then stalled at issue (tools/attn_stamps.py:
 // prefetch issue 2.5k + stores 1.7k of 11k cycles per item).
-template <int NSUB>
+template <int NSUB, bool O8 = false>
 __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv, const bf16x8 (&qf)[4],
                                                   const AttnArgs& a, int b, int head, int qbase, int lane,
                                                   char* so = nullptr) {
@@ -307,6 +319,34 @@ __device__ __forceinline__ void attn_tile_compute(const char* sk, const char* sv
   // per-item barrier of the persistent kernel does not have to wait with vmcnt(0) - gfx9 counts stores in
   // vmcnt too, and a wait after them exposes the whole write latency once per item.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  if constexpr (O8) {
+    // e4m3 output (so is never NULL here): the 32 x 64-byte tile through 2 KiB of the wave's staging area - the lane's
+    // dwords d = 8 t + 4 h .. + 3 of both 32-column halves, 16-byte chunk c of row r at ((c ^ ((r >> 2) & 3)) << 4) -
+    // and out as 16 rows x 64 bytes per instruction (a token's head slice is half a line: nothing wider exists)
+    const float sc = inv * a.oinv;
+    const int key = (l31 >> 2) & 3;
+    char* wr = so + l31 * 64 + 4 * (h & 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned w0 = attn_pack4_e4m3(o0[4 * t] * sc, o0[4 * t + 1] * sc, o0[4 * t + 2] * sc, o0[4 * t + 3] * sc);
+      const unsigned w1 = attn_pack4_e4m3(o1[4 * t] * sc, o1[4 * t + 1] * sc, o1[4 * t + 2] * sc, o1[4 * t + 3] * sc);
+      // byte 8 t + 4 h of the half: chunk t >> 1, dword 2 (t & 1) + h inside it
+      *reinterpret_cast<unsigned*>(wr + (((t >> 1) ^ key) << 4) + 8 * (t & 1)) = w0;
+      *reinterpret_cast<unsigned*>(wr + (((2 + (t >> 1)) ^ key) << 4) + 8 * (t & 1)) = w1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int u = lane & 3;
+    unsigned char* ob = a.out8 + ((long)b * np + qbase) * C + head * 64 + u * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (lane >> 2) + 16 * j;
+      const uint4 v = *reinterpret_cast<const uint4*>(so + r * 64 + ((u ^ ((r >> 2) & 3)) << 4));
+      if (qbase + r < np) *reinterpret_cast<uint4*>(ob + (long)r * C) = v;
+    }
+    if (head == 0 && h == 0 && q < np) a.row_scale[(long)b * np + q] = a.oscale;
+    return;
+  }
   if (so != nullptr) {
     // staging image: row r = query, sixteen 8-byte units per row, 16-byte unit u at ((u ^ key(r)) << 4)
     const int key = (l31 ^ (l31 >> 3)) & 7;
@@ -419,11 +459,12 @@ __device__ __forceinline__ void dma16(const char* base, unsigned off, char* dst)
 
 // G: rows are gathered through keep_idx (a.idx != NULL) - a template flag, so that the per-item prefetch
 // carries no pointer tests (they were 10 scalar branches per item).
-template <int NSUB, bool G>
+template <int NSUB, bool G, bool O8 = false>
 __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const AttnArgs a, int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NSUB * 32, BUF = ROWS * 256, NP8 = ROWS / 8;   // pieces (8 rows) per operand
-  constexpr bool STAGE_O = stage_o(NSUB);
+  constexpr bool STAGE_O = O8 || stage_o(NSUB);      // (e4m3 output always leaves through its 2 KiB-per-wave staging area)
+  constexpr int STAGE_BYTES = O8 ? 2048 : 4096;
   constexpr int PER_WAVE = (NP8 + 7) / 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,8 +577,8 @@ __global__ void __launch_bounds__(ATF_THREADS, 2) attn_bf16_d64_stream(const Att
 #endif
     if (active) {
       const int b = cb, head = chead;
-      attn_tile_compute<NSUB>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane,
-                              STAGE_O ? smem + 2 * BUF + (qbase >> 5) * 4096 : nullptr);
+      attn_tile_compute<NSUB, O8>(smem + buf * BUF, smem + buf * BUF + ROWS * 128, qf, a, b, head, qbase, lane,
+                                  STAGE_O ? smem + 2 * BUF + (qbase >> 5) * STAGE_BYTES : nullptr);
     }
 #ifdef RAJNI_ATTN_STAMPS
     if (a.stamps != nullptr && qbase == 0 && lane == 0) {   // wave 0: [0] barrier arrival, [3] released, [4] prefetch issued, [5] tile done
@@ -905,6 +946,30 @@ __global__ void __launch_bounds__(256) attn_f32_dgen(const AttnArgsF32 a, int D)
 int g_force_attn = 0;  // 0 auto (persistent), 1 chunked online-softmax kernel, 2 one-shot full-row kernel (tests)
 
 template <int NSUB>
+int launch_full_o8(const AttnArgs& a, int B, hipStream_t s) {   // e4m3 output: persistent kernel only, 2 KiB staging per wave
+  constexpr int lds = NSUB * 32 * 256 * 2 + 8 * 2048;
+  static bool attr_by_device[RAJNI_MAX_DEVICES] = {};
+  bool& attr = attr_by_device[rajni_current_device()];
+  if (!attr && lds > 64 * 1024) {
+    for (const void* fn : {reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, false, true>),
+                           reinterpret_cast<const void*>(&attn_bf16_d64_stream<NSUB, true, true>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) { rajni_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e)); return RAJNI_ERR_LAUNCH; }
+    }
+    attr = true;
+  }
+  const int per_cu = (160 * 1024) / lds >= 2 ? 2 : 1;
+  const int items = a.H * B;
+  const int cus = rajni_num_cus();
+  const int grid = items < cus * per_cu ? items : cus * per_cu;
+  if (a.idx != nullptr)
+    hipLaunchKernelGGL((attn_bf16_d64_stream<NSUB, true, true>), dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
+  else
+    hipLaunchKernelGGL((attn_bf16_d64_stream<NSUB, false, true>), dim3(grid), dim3(ATF_THREADS), lds, s, a, items);
+  return RAJNI_OK;
+}
+
+template <int NSUB>
 int launch_full(const AttnArgs& a, int B, hipStream_t s) {
   if (g_force_attn == 2) {
     constexpr int lds = NSUB * 32 * 128 * 2;
@@ -942,7 +1007,7 @@ int launch_full(const AttnArgs& a, int B, hipStream_t s) {
 // fp32 math on the stored activations (P is not rounded to bf16 here).  D % 8 == 0, D <= 128.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(64) attn_cls_kernel(const T* qkv, T* out, int N, int H, int D, float c) {
+__global__ void __launch_bounds__(64) attn_cls_kernel(const T* qkv, T* out, int N, int H, int D, float c, float q_scale) {
   extern __shared__ __attribute__((aligned(16))) float cls_sm[];
   float* qs = cls_sm;                // [D]
   float* prob = cls_sm + D;          // [N]
@@ -978,21 +1043,26 @@ __global__ void __launch_bounds__(64) attn_cls_kernel(const T* qkv, T* out, int 
     float acc = 0.f;
     const T* vc = img + 2 * C + d;
     for (int n = 0; n < N; ++n) acc = fmaf(prob[n], ld1(vc + (long)n * C3), acc);
-    st1(out + (long)b * C + head * D + d, acc / sum);
+    float o = acc / sum;
+    if (q_scale > 0.f) {   // the rounding rajni_attention_fp8 applies to this row in the all-rows form of the block
+      const float t = __builtin_amdgcn_fmed3f(o * (1.0f / q_scale), -448.f, 448.f);
+      o = __builtin_amdgcn_cvt_f32_fp8(__builtin_amdgcn_cvt_pk_fp8_f32(t, 0.f, 0, false), 0) * q_scale;
+    }
+    st1(out + (long)b * C + head * D + d, o);
   }
 }
 
 int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,
-                         hipStream_t s) {
+                         hipStream_t s, float q_scale) {
   RAJNI_REQUIRE(qkv && out && D >= 8 && D <= 128 && D % 8 == 0 && B > 0 && H > 0 && N > 0 && B <= 65535 &&
                 (size_t)(N + D) * sizeof(float) <= 64 * 1024, RAJNI_ERR_INVALID, "attention_cls: bad arguments");
   const float c = scale * 1.4426950408889634f;
   const size_t lds = (size_t)(N + D) * sizeof(float);
   ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)N * D, 2.0 * B * (double)N * H * D * (dtype == RAJNI_F32 ? 4.0 : 2.0));
   if (dtype == RAJNI_F32)
-    hipLaunchKernelGGL(attn_cls_kernel<float>, dim3(H, B), dim3(64), lds, s, (const float*)qkv, (float*)out, N, H, D, c);
+    hipLaunchKernelGGL(attn_cls_kernel<float>, dim3(H, B), dim3(64), lds, s, (const float*)qkv, (float*)out, N, H, D, c, 0.f);
   else
-    hipLaunchKernelGGL(attn_cls_kernel<bf16_t>, dim3(H, B), dim3(64), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, H, D, c);
+    hipLaunchKernelGGL(attn_cls_kernel<bf16_t>, dim3(H, B), dim3(64), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, H, D, c, q_scale);
   RAJNI_CHECK_LAUNCH("attn_cls_kernel");
   return RAJNI_OK;
 }
@@ -1057,6 +1127,40 @@ int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B,
                        s, a);
   }
   RAJNI_CHECK_LAUNCH("attn_bf16_d64");
+  return RAJNI_OK;
+}
+
+// attention with e4m3 output rows (rajni_attention_fp8): bf16 qkv, head dim 64, np <= 224 (the persistent kernel with
+// LDS to spare for the output staging)
+int launch_attention_fp8(const void* qkv, const int32_t* keep_idx, void* out_q, float out_scale, float* row_scale,
+                         int B, int n_src, int np, int H, int D, float scale, hipStream_t s) {
+  RAJNI_REQUIRE(qkv && out_q && row_scale, RAJNI_ERR_INVALID, "rajni_attention_fp8: null pointer");
+  RAJNI_REQUIRE(D == 64 && np <= 224, RAJNI_ERR_UNSUPPORTED,
+                "rajni_attention_fp8: head dim 64 and at most 224 tokens (D=%d np=%d)", D, np);
+  RAJNI_REQUIRE(B > 0 && H > 0 && np > 0 && n_src >= np, RAJNI_ERR_INVALID,
+                "rajni_attention_fp8: bad shape B=%d H=%d np=%d n_src=%d", B, H, np, n_src);
+  RAJNI_REQUIRE(keep_idx != nullptr || np == n_src, RAJNI_ERR_INVALID,
+                "rajni_attention_fp8: identity selection needs np == n_src");
+  RAJNI_REQUIRE(out_scale > 0.f && out_scale < INFINITY, RAJNI_ERR_INVALID, "rajni_attention_fp8: out_scale must be positive and finite");
+  AttnArgs a{};
+  a.qkv = (const bf16_t*)qkv; a.idx = keep_idx; a.out = nullptr;
+  a.n_src = n_src; a.np = np; a.H = H;
+  a.c = scale * 1.4426950408889634f;
+  a.stamps = nullptr;
+  a.out8 = (unsigned char*)out_q; a.oscale = out_scale; a.oinv = 1.0f / out_scale; a.row_scale = row_scale;
+  ProfScope prof(KC_ATTENTION, s, 4.0 * B * H * (double)np * np * D, 2.0 * B * (double)np * H * D * 3.5);
+  int rc = RAJNI_OK;
+  switch ((np + 31) / 32) {
+    case 1: rc = launch_full_o8<1>(a, B, s); break;
+    case 2: rc = launch_full_o8<2>(a, B, s); break;
+    case 3: rc = launch_full_o8<3>(a, B, s); break;
+    case 4: rc = launch_full_o8<4>(a, B, s); break;
+    case 5: rc = launch_full_o8<5>(a, B, s); break;
+    case 6: rc = launch_full_o8<6>(a, B, s); break;
+    default: rc = launch_full_o8<7>(a, B, s); break;
+  }
+  if (rc != RAJNI_OK) return rc;
+  RAJNI_CHECK_LAUNCH("attn_bf16_d64_stream<e4m3 out>");
   return RAJNI_OK;
 }
 

@@ -26,7 +26,8 @@ const char* const kNames[RAJNI_NUM_KCLASS] = {
     "gemm_bf16_tn<patch>", "attn_bf16_d64", "layernorm_kernel", "score_select_kernel<fused>",
     "score_select_kernel<scores>", "score_select_kernel<select>", "gather_rows_kernel",
     "cls_pos_kernel", "other", "gemm_bf16_tn<bias,ls,resid> K<=N",
-    "gemm_f8_tn<bias>", "gemm_f8_tn<bias,gelu,requant>", "gemm_f8_tn<bias,ls,resid>"};
+    "gemm_f8_tn<bias>", "gemm_f8_tn<bias,gelu,requant>", "gemm_f8_tn<bias,ls,resid>",
+    "gemm_f8_tn<bias,ls,resid> K<=N"};
 }  // namespace
 
 unsigned long long* rajni_g_stamps = nullptr;
@@ -137,6 +138,11 @@ int rajni_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, 
                     int H, int D, float scale, int dtype, rajni_stream_t stream) {
   NEED_DTYPE("rajni_attention");
   return launch_attention(qkv, keep_idx, out, B, n_src, np, H, D, scale, dtype, (hipStream_t)stream);
+}
+
+extern "C" int rajni_attention_fp8(const void* qkv, const int32_t* keep_idx, void* out_q, float out_scale, float* row_scale,
+                                   int B, int n_src, int np, int H, int D, float scale, rajni_stream_t stream) {
+  return launch_attention_fp8(qkv, keep_idx, out_q, out_scale, row_scale, B, n_src, np, H, D, scale, (hipStream_t)stream);
 }
 
 int rajni_layernorm(const void* x, long x_row_stride, const float* w, const float* b, void* y,

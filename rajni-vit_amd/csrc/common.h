@@ -90,7 +90,8 @@ enum KClass {
   KC_LAYERNORM = 5, KC_SCORE_SELECT = 6, KC_IMPORTANCE = 7, KC_SELECT = 8, KC_GATHER = 9,
   KC_CLS_POS = 10, KC_OTHER = 11,
   KC_GEMM_RESID_SQ = 12,  // residual GEMM with K <= N (the attention projection): bound by its fp32-stream epilogue
-  KC_GEMM8_BIAS = 13, KC_GEMM8_GELU = 14, KC_GEMM8_RESID = 15   // fp8 x fp8 GEMMs (act_fp8 plans)
+  KC_GEMM8_BIAS = 13, KC_GEMM8_GELU = 14, KC_GEMM8_RESID = 15,  // fp8 x fp8 GEMMs (act_fp8 plans)
+  KC_GEMM8_RESID_SQ = 16   // ... with K <= N (proj on e4m3 attention output)
 };
 // event bracket around one launch when the class is enabled
 struct ProfScope {
@@ -131,8 +132,10 @@ int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b,
                          float* hscale, float wnorm, float bmax, int rows, int C, float eps, int x_f32, hipStream_t s);
 int launch_attention(const void* qkv, const int32_t* keep_idx, void* out, int B, int n_src, int np,
                      int H, int D, float scale, int dtype, hipStream_t s);
+int launch_attention_fp8(const void* qkv, const int32_t* keep_idx, void* out_q, float out_scale, float* row_scale,
+                         int B, int n_src, int np, int H, int D, float scale, hipStream_t s);
 int launch_attention_cls(const void* qkv, void* out, int B, int N, int H, int D, float scale, int dtype,
-                         hipStream_t s);
+                         hipStream_t s, float q_scale = 0.f);   // q_scale > 0: the row passes through rajni_attention_fp8's e4m3 rounding
 int launch_score_select(const void* qkv, const void* scores_in, int B, int N, int H, int D,
                         float eps, int keep, void* scores_out, int32_t* keep_idx,
                         void* next_scores, int dtype, hipStream_t s);

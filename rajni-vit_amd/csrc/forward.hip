@@ -123,7 +123,9 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     if (p.cls_only_last_block && i == p.depth - 1 && blk.keep == 0 && N > 1) {
       // ---- last block, not a pruning stage, caller opted in: only x[:, 0] reaches the head (model.py:65-66),
       //      so attention runs for the CLS query alone (over all N keys) and proj / MLP on the B CLS rows
-      rc = launch_attention_cls(w.qkv, w.att, B, N, p.H, p.D, p.attn_scale, dt, s);
+      // (an act_fp8 block whose all-rows form would emit e4m3 attention rows rounds the CLS row the same way)
+      const bool att8c = p.act_fp8 && blk.attn_out_scale > 0.f && blk.proj_s != nullptr && p.D == 64 && N <= 224;
+      rc = launch_attention_cls(w.qkv, w.att, B, N, p.H, p.D, p.attn_scale, dt, s, att8c ? blk.attn_out_scale : 0.f);
       if (rc != RAJNI_OK) return rc;
       g = rajni_linear_args{};
       g.dtype = dt;
@@ -196,7 +198,11 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     }
 
     // ---- attention on the kept tokens, gather fused (attention.py:42-54)
-    rc = launch_attention(w.qkv, idx, w.att, B, N, Np, p.H, p.D, p.attn_scale, dt, s);
+    // act_fp8 plans: e4m3 output rows + their (one) scale into w.xs - norm1's row scales there were consumed by QKV -
+    // wherever the persistent head-dim-64 kernel serves the launch (rajni_attention_fp8); proj then runs fp8 x fp8
+    const bool att8 = p.act_fp8 && blk.attn_out_scale > 0.f && blk.proj_s != nullptr && p.D == 64 && Np <= 224;
+    if (att8) rc = launch_attention_fp8(w.qkv, idx, w.att, blk.attn_out_scale, w.xs, B, N, Np, p.H, p.D, p.attn_scale, s);
+    else rc = launch_attention(w.qkv, idx, w.att, B, N, Np, p.H, p.D, p.attn_scale, dt, s);
     if (rc != RAJNI_OK) return rc;
 
     // ---- proj + (gathered) residual + LayerScale (attention.py:55-56, model.py:55-58)
@@ -205,6 +211,7 @@ extern "C" int rajni_vit_forward(const rajni_vit_plan* plan, const void* images,
     g.dtype = dt;
     g.x = w.att; g.lda = C; g.w = blk.proj_w; g.ldw = C; g.bias = blk.proj_b; g.gamma = blk.ls1; g.w_scale = blk.proj_s;
     g.resid = cur; g.ldr = C; g.M = Mp; g.N = C; g.K = C; g.epilogue = RAJNI_EPI_BIAS_RESID; g.stream_f32 = sf32;
+    if (att8) g.x_scale = w.xs;
     if (idx) {
       g.r_idx = idx; g.r_np = Np; g.r_nsrc = N;
       g.y = oth; g.ldc = C;

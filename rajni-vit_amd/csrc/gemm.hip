@@ -1542,8 +1542,8 @@ int launch_linear(const rajni_linear_args& a, hipStream_t s) {
       case RAJNI_EPI_BIAS_RESID:
         RAJNI_REQUIRE(a.resid != nullptr && a.ldr % 8 == 0 && a.y_scale == nullptr, RAJNI_ERR_INVALID,
                       "rajni_linear: RESID epilogue needs resid, ldr %% 8 == 0 and no y_scale");
-        return a.stream_f32 ? launch_gemm_f8<EPI_RESID, true>(p, KC_GEMM8_RESID, a.K <= a.N, s)
-                            : launch_gemm_f8<EPI_RESID, false>(p, KC_GEMM8_RESID, a.K <= a.N, s);
+        return a.stream_f32 ? launch_gemm_f8<EPI_RESID, true>(p, a.K <= a.N ? KC_GEMM8_RESID_SQ : KC_GEMM8_RESID, a.K <= a.N, s)
+                            : launch_gemm_f8<EPI_RESID, false>(p, a.K <= a.N ? KC_GEMM8_RESID_SQ : KC_GEMM8_RESID, a.K <= a.N, s);
       default:
         rajni_set_error("rajni_linear: unknown epilogue %d", a.epilogue);
         return RAJNI_ERR_INVALID;

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RAJNI_HIP_LIB") or os.path.join(_HERE, "lib", "libraj
 
 RAJNI_F32, RAJNI_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2
-NUM_KCLASS = 16
+NUM_KCLASS = 17
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -45,7 +45,7 @@ class Block(C.Structure):
                 ("keep_idx", c_void_p), ("scores", c_void_p), ("next_scores", c_void_p),
                 ("forced_keep_idx", c_void_p),
                 ("qkv_s", c_void_p), ("proj_s", c_void_p), ("fc1_s", c_void_p), ("fc2_s", c_void_p),
-                ("fc1_rownorm_max", c_float), ("fc1_bias_absmax", c_float)]
+                ("fc1_rownorm_max", c_float), ("fc1_bias_absmax", c_float), ("attn_out_scale", c_float)]
 
 
 class VitPlan(C.Structure):
@@ -72,6 +72,8 @@ _SIGS = {
     "rajni_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rajni_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_int, c_void_p]),
+    "rajni_attention_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    c_void_p]),
     "rajni_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                 c_int, c_int, c_void_p]),
     "rajni_layernorm_fp8": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
@@ -97,7 +99,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
-ABI_VERSION = 7     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
+ABI_VERSION = 8     # include/rajni_hip.h; bumped whenever a struct or an entry point changes
 _lib: Optional[C.CDLL] = None
 
 

@@ -153,6 +153,41 @@ def attention(qkv: torch.Tensor, keep_idx: Optional[torch.Tensor], num_heads: in
     return out
 
 
+def attention_out_scale(norm1_w: torch.Tensor, norm1_b: torch.Tensor, wv: torch.Tensor, bv: Optional[torch.Tensor]) -> float:
+    """out_scale of `attention_fp8` from a block's parameters (the bound of rajni_attention_fp8, include/rajni_hip.h):
+    (1.0625 * (sqrt(C) * max|gamma1| + ||beta1||_2) * max_c ||Wv[c]||_2 + max|bv|) / 448, evaluated in fp32.
+    `wv` are the V rows of the qkv weight AS THE KERNELS HOLD THEM (dequantised e4m3), [C, C]."""
+    g, b = norm1_w.detach().to(torch.float32), norm1_b.detach().to(torch.float32)
+    w32 = wv.detach().to(torch.float32)
+    c = torch.tensor(float(w32.shape[1]), dtype=torch.float32).sqrt()
+    bound = torch.tensor(1.0625, dtype=torch.float32) * (c * g.abs().max().cpu() + b.norm().cpu()) * w32.norm(dim=1).max().cpu()
+    if bv is not None:
+        bound = bound + bv.detach().to(torch.float32).abs().max().cpu()
+    return float(bound / torch.tensor(448.0, dtype=torch.float32))
+
+
+def attention_fp8(qkv: torch.Tensor, keep_idx: Optional[torch.Tensor], num_heads: int, scale: float, out_scale: float):
+    """attention with e4m3 output rows (opt-in fp8_mfma format): qkv bf16 [B, N, 3C], head dim 64, at most 224 kept tokens
+    -> (bytes uint8 [B, Np, C] = e4m3_rne_sat(attn / out_scale), row scales fp32 [B * Np] = out_scale)"""
+    nat.require_device(qkv, "qkv")
+    qkv = qkv.contiguous()
+    B, N, threeC = qkv.shape
+    Cc = threeC // 3
+    D = Cc // num_heads
+    if keep_idx is not None:
+        keep_idx = keep_idx.to(torch.int32).contiguous()
+        Np = keep_idx.shape[1]
+    else:
+        Np = N
+    out = torch.empty((B, Np, Cc), dtype=torch.uint8, device=qkv.device)
+    rs = torch.empty(B * Np, dtype=torch.float32, device=qkv.device)
+    with nat.device_guard(qkv.device):
+        nat.check(nat.lib().rajni_attention_fp8(qkv.data_ptr(), nat.ptr(keep_idx), out.data_ptr(), float(out_scale), rs.data_ptr(),
+                                                B, N, Np, num_heads, D, float(scale), nat.stream_ptr(qkv.device)),
+                  "rajni_attention_fp8")
+    return out, rs
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, rows: Optional[int] = None,
               row_stride: Optional[int] = None, out_dtype=torch.bfloat16) -> torch.Tensor:
     """LayerNorm over the last axis; w, b fp32.  x may be `out_dtype` or fp32 (the fp32 residual

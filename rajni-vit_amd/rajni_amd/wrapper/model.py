@@ -315,6 +315,11 @@ class RAJNIViTWrapper(nn.Module):
                 wd = ops.dequantize_fp8(fc1_w, fc1_s)
                 blocks[-1]["fc1_rownorm_max"] = float(wd.norm(dim=1).max())
                 blocks[-1]["fc1_bias_absmax"] = float(fc1_b.abs().max())
+                # the one scale of the e4m3 attention output (rajni_attention_fp8), from the V rows of the dequantised qkv weight
+                C = desc["C"]
+                vd = ops.dequantize_fp8(qkv_w, qkv_s)[2 * C:3 * C]
+                blocks[-1]["attn_out_scale"] = ops.attention_out_scale(blocks[-1]["norm1_w"], blocks[-1]["norm1_b"], vd,
+                                                                       blocks[-1]["qkv_b"][2 * C:3 * C])
         W["blocks"] = blocks
         self._weights, self._weights_key = W, key
         self._weights_sig, self._weights_cfg = sig, cfg_key
@@ -352,6 +357,7 @@ class RAJNIViTWrapper(nn.Module):
                 setattr(cb, name, nat.ptr(bw[name]))
             if self._weight_format == "fp8_mfma":
                 cb.fc1_rownorm_max, cb.fc1_bias_absmax = bw["fc1_rownorm_max"], bw["fc1_bias_absmax"]
+                cb.attn_out_scale = bw["attn_out_scale"]
             if i in self.pruning_schedule:
                 cfg = self.pruning_schedule[i]
                 N = counts[i]
