@@ -50,7 +50,7 @@ PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA (same table; never the 2:1-sparsity
 PEAK_HBM_GBS = 8000.0
 L384_SCHEDULE = {4: {"keep_ratio": 0.7, "update": True}, 12: {"keep_ratio": 0.5, "update": True},
                  20: {"keep_ratio": 0.3, "update": True}}          # BASELINE.json configs[3]
-GEMM_MASK = 0b0111 | (1 << 12) | (0b111 << 13)   # kernel classes: qkv/head, fc1, fc2 (K > N), proj (K <= N), fp8 x fp8 twins
+GEMM_MASK = 0b0111 | (1 << 12) | (0b1111 << 13)   # kernel classes: qkv/head, fc1, fc2 (K > N), proj (K <= N), fp8 x fp8 twins (13..16)
 
 
 def flops_per_image(cfg, schedule):

@@ -61,6 +61,73 @@ def test_layernorm_fp8_rule(rows, Cc, x_f32):
     np.testing.assert_allclose(hs.cpu().numpy(), hs_ref, rtol=2e-5)
 
 
+@pytest.mark.parametrize("B,N,Np,H", [(2, 197, 173, 12), (3, 17, 13, 2), (2, 87, 87, 3), (1, 152, 121, 3), (2, 224, 224, 2),
+                                      (1, 40, 33, 2), (2, 197, 197, 12)])
+@pytest.mark.parametrize("loose", [1.0, 24.0])
+def test_attention_fp8_output_rule(B, N, Np, H, loose):
+    """rajni_attention_fp8: rows = e4m3_rne_sat(attention * (1 / out_scale)) with ONE given scale (a bound; `loose` = how far
+    above the true maximum it sits - e4m3 is a floating-point format, a loose bound costs range, not precision), the same
+    scale in every row-scale slot; everything else (gather, softmax, products) as rajni_attention."""
+    rng = np.random.default_rng(N * 31 + Np + H)
+    Cc = H * 64
+    qkv = bf16_round_np(rng.standard_normal((B, N, 3 * Cc), dtype=np.float32))
+    if Np == N:
+        idx_t, g = None, qkv
+    else:
+        idx = np.stack([np.concatenate([[0], 1 + np.sort(rng.choice(N - 1, Np - 1, replace=False))]) for _ in range(B)])
+        idx_t = torch.from_numpy(idx.astype(np.int32)).to(DEV)
+        g = orc.gather_rows(qkv, idx.astype(np.int64))
+    q, k, v = orc.split_heads(g.astype(np.float64), H)
+    want = orc.softmax_attention(q, k, v, 64 ** -0.5)
+    scale = float(np.float32(np.abs(want).max() * loose / 448.0))
+    xb = torch.from_numpy(qkv).to(DEV).to(torch.bfloat16)
+    out, rs = ops.attention_fp8(xb, idx_t, H, 64 ** -0.5, scale)
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (B, Np, Cc)
+    assert (rs.cpu().numpy() == np.float32(scale)).all()
+    deq = e4m3_bytes_to_f64(out) * np.float64(np.float32(scale))
+    ref = ops.attention(xb, idx_t, H, 64 ** -0.5).float().cpu().numpy().astype(np.float64)     # the bf16-output kernel: same products
+    # e4m3: half an ulp = 2^-4 relative in the normal range, scale * 2^-10 absolute below it; on top, what separates the two
+    # kernels' own roundings of the same fp32 value (bf16 output: 2^-9 relative)
+    bound = np.maximum(np.abs(ref) * 2.0 ** -4, scale * 2.0 ** -10) * 1.001 + np.abs(ref) * 2.0 ** -8 + 1e-6 * np.abs(want).max()
+    assert (np.abs(deq - ref) <= bound).all(), float((np.abs(deq - ref) - bound).max())
+    assert np.abs(deq - want).max() <= (2.0 ** -4 + 1.5e-2) * np.abs(want).max()
+    # byte for byte the stated rule applied to the bf16 kernel's output, except where that output sits within its own
+    # rounding of an e4m3 boundary
+    rule = orc.quantize_rows_e4m3(ref, np.float32(scale))
+    assert np.mean(rule != deq) < 0.08
+
+
+def test_attention_fp8_refuses_what_it_does_not_serve():
+    x = torch.zeros(1, 230, 3 * 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="224"):
+        ops.attention_fp8(x, None, 1, 0.125, 1.0)
+    x = torch.zeros(1, 40, 3 * 96, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        ops.attention_fp8(x, None, 1, 0.1, 1.0)            # head dim 96
+    x = torch.zeros(1, 40, 3 * 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(nat.NativeError):
+        ops.attention_fp8(x, None, 1, 0.125, 0.0)          # a scale must be positive
+
+
+def test_attention_out_scale_is_a_bound_and_matches_the_oracle():
+    """ops.attention_out_scale (packed with the weights) restated by oracle.attention_out_scale, and really a bound: the
+    largest |attention output| of a random block whose LayerNorm feeds V stays below 448 * scale."""
+    rng = np.random.default_rng(11)
+    Cc, H, B, N = 256, 4, 2, 50
+    g = (1 + 0.2 * rng.standard_normal(Cc)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    wv = (0.05 * rng.standard_normal((Cc, Cc))).astype(np.float32)
+    bv = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    s_dev = ops.attention_out_scale(torch.from_numpy(g), torch.from_numpy(be), torch.from_numpy(wv), torch.from_numpy(bv))
+    s_orc = float(orc.attention_out_scale(g, be, wv, bv))
+    assert abs(s_dev - s_orc) <= 4e-6 * s_orc
+    x = rng.standard_normal((B, N, Cc)) * rng.uniform(0.1, 20.0, size=(B, N, 1))
+    ln = orc.layer_norm(x, g.astype(np.float64), be.astype(np.float64), 1e-6)
+    ln = orc.quantize_rows_e4m3(ln, orc.row_scale_e4m3(ln))
+    v = ln @ wv.astype(np.float64).T + bv
+    assert np.abs(v).max() <= 448.0 * s_orc
+
+
 def _f8_operands(rng, M, N, K):
     xq, wq = random_e4m3(rng, (M, K)), random_e4m3(rng, (N, K))
     # keep products tame: scales so that dequantised entries are O(1)
@@ -209,7 +276,9 @@ def test_forward_fp8_mfma_vs_oracle_micro(batch):
 def test_forward_fp8_mfma_single_block_is_tight():
     """With ONE block the inputs of the first two quantisation points agree to fp32 rounding between device and oracle,
     so the rule can be checked end to end without the chaos of a deep stack: qkv sees bit-equal e4m3 rows (up to
-    boundary cases) and the logits must agree far inside the rule's own effect."""
+    boundary cases) and the logits must agree inside the rule's own effect.  (The attention-output point is different:
+    the device's attention is a bf16-operand computation, ~1e-2 from the oracle's fp64 one, so a few per cent of its
+    elements land on the other side of an e4m3 boundary - a 2^-3 relative step each - which is most of what is left.)"""
     import dataclasses
     cfg = dataclasses.replace(ts.CONFIGS["vit_micro512_patch16_64"], depth=1)
     model = ts.create_model(cfg, seed=6, std=0.06, bias_std=0.02, round_bf16=True)
@@ -220,8 +289,12 @@ def test_forward_fp8_mfma_single_block_is_tight():
     with_act, weights_only, _ = _oracle_fp8(cfg, model, w, imgs, {}, None)
     scale = float(np.abs(weights_only).max())
     err, cost = float(np.abs(got - with_act).max()), float(np.abs(with_act - weights_only).max())
-    print(f"\nfp8_mfma depth 1: device vs oracle-with-the-rule {err / scale:.4g} rel, the rule's own effect {cost / scale:.4g} rel")
-    assert err <= 0.5 * cost + 1e-2 * scale
+    r_err = float(np.sqrt(np.mean((got - with_act) ** 2)))
+    r_cost = float(np.sqrt(np.mean((with_act - weights_only) ** 2)))
+    print(f"\nfp8_mfma depth 1: device vs oracle-with-the-rule {err / scale:.4g} rel (rms {r_err / scale:.4g}), the rule's own effect "
+          f"{cost / scale:.4g} rel (rms {r_cost / scale:.4g})")
+    assert err <= 0.8 * cost + 1e-2 * scale
+    assert r_err <= 0.7 * r_cost + 2e-3 * scale
 
 
 @pytest.mark.parametrize("name", ["base224_fp32", "deit3_fp32", "large384_fp32"])

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert set(nat.EXPORTED_SYMBOLS) == declared
-    assert lib.rajni_abi_version() == nat.ABI_VERSION == 7
+    assert lib.rajni_abi_version() == nat.ABI_VERSION == 8
     assert lib.rajni_profile_class_name(0).decode().startswith("gemm")
 
 
@@ -73,7 +73,7 @@ def test_struct_layouts_match_header_sizes():
     plan.resid_bf16 = 0
     plan.act_fp8 = 1        # two per-row scale vectors
     assert nat.lib().rajni_vit_workspace_bytes(C.byref(plan)) == want + 2 * a256(rows * 4)
-    plan.act_fp8 = 0        # (the LAST int of the struct, ABI 7: the whole layout lines up)
+    plan.act_fp8 = 0        # (the LAST int of the struct, ABI 8: the whole layout lines up)
 
 
 def test_no_cpu_fallback():

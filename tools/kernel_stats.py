@@ -16,6 +16,8 @@ for name, dur in rows:
         name += " [K<=N: bench class gemm_bf16_tn<bias,ls,resid> K<=N]"
     elif re.search(r"gemm_bf16_tn_stream<2,", name):
         name += " [K>N: bench class gemm_bf16_tn<bias,ls,resid>]"
+    elif re.search(r"gemm_f8_tn_stream<2, (?:true|false), 1>\(", name):   # proj on e4m3 attention output
+        name += " [K<=N: bench class gemm_f8_tn<bias,ls,resid> K<=N]"
     a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
     a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
 total = sum(a[1] for a in agg.values())

@@ -16,6 +16,7 @@ from srchash import csrc_fingerprint  # noqa: E402
 
 BENCH_CLASS = {0: "gemm_bf16_tn<bias>", 1: "gemm_bf16_tn<bias,gelu>", 2: "gemm_bf16_tn<bias,ls,resid>", 3: "gemm_bf16_tn<patch>"}
 RESID_SQ = "gemm_bf16_tn<bias,ls,resid> K<=N"   # the projection: same kernel as fc2, an instantiation of its own (TAG = 1)
+F8_RESID_SQ = "gemm_f8_tn<bias,ls,resid> K<=N"    # proj on e4m3 attention output (TAG = 1)
 F8_CLASS = {0: "gemm_f8_tn<bias>", 4: "gemm_f8_tn<bias,gelu,requant>", 2: "gemm_f8_tn<bias,ls,resid>"}
 CHECK_CLASSES = ("gemm_bf16_tn<bias,gelu>", "gemm_f8_tn<bias,gelu,requant>")   # FC1 (MFMA count): one shape family, nothing else in the class
 WRITE_CHECK_CLASSES = ("gemm_bf16_tn<bias>", "gemm_f8_tn<bias>")              # QKV (+ the head in the bf16 class): output bytes
@@ -37,7 +38,7 @@ def bench_class(name):
         return RESID_SQ if name.endswith("[proj]") else BENCH_CLASS[int(m.group(1))]
     m8 = re.search(r"gemm_f8_tn_(?:stream|wide)<(\d)", name)
     if m8:
-        return F8_CLASS[int(m8.group(1))]
+        return F8_RESID_SQ if name.endswith("[proj]") else F8_CLASS[int(m8.group(1))]
     return None
 
 
