@@ -79,6 +79,32 @@ __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
   const f32x2 h = xc * q;
   return x * h + x * f32x2{0.5f, 0.5f};
 }
+// the same for two pairs at once, the two Horner chains interleaved statement by statement: a packed fp32 op that reads the
+// result of the one issued right before it costs a wait state (hipcc pads with s_nop 0: the single-chain form had one
+// behind almost every v_pk_fma_f32 - ~600 per tile and wave, a quarter on top of the epilogue's VALU time); two
+// independent chains fill each other's slots.  Same operations per element: bit-identical results.
+__device__ __forceinline__ void gelu_pk4(f32x2& a, f32x2& b) {
+  const float X0 = 4.24264069f;
+  const f32x2 lo = f32x2{-X0, -X0}, hi = f32x2{X0, X0};
+  const f32x2 ac = __builtin_elementwise_min(__builtin_elementwise_max(a, lo), hi);
+  const f32x2 bc = __builtin_elementwise_min(__builtin_elementwise_max(b, lo), hi);
+  const f32x2 ua = ac * ac, ub = bc * bc;
+  f32x2 qa = f32x2{5.405088552e-11f, 5.405088552e-11f}, qb = qa;
+#define RAJNI_GELU_STEP(c) { const f32x2 k = f32x2{c, c}; qa = qa * ua + k; qb = qb * ub + k; }
+  RAJNI_GELU_STEP(-5.202485173e-09f)
+  RAJNI_GELU_STEP(2.215015442e-07f)
+  RAJNI_GELU_STEP(-5.557312053e-06f)
+  RAJNI_GELU_STEP(9.274613401e-05f)
+  RAJNI_GELU_STEP(-1.104852507e-03f)
+  RAJNI_GELU_STEP(9.805144109e-03f)
+  RAJNI_GELU_STEP(-6.633033261e-02f)
+  RAJNI_GELU_STEP(3.988969665e-01f)
+#undef RAJNI_GELU_STEP
+  const f32x2 ha = ac * qa, hb = bc * qb;
+  const f32x2 half = f32x2{0.5f, 0.5f};
+  const f32x2 ya = a * ha + a * half, yb = b * hb + b * half;
+  a = ya; b = yb;
+}
 
 // load / store 16 consecutive stream elements (bf16 or fp32) as floats
 template <bool F32>
@@ -150,9 +176,10 @@ __device__ __forceinline__ void epilogue_row(const GemmParams& p, int m, int nbA
   const bool full = nbB + 8 <= p.N;   // both halves inside N (nbA < nbB)
   if (EPI == EPI_GELU) {
 #pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const f32x2 y = gelu_pk(f32x2{v[j], v[j + 1]});
-      v[j] = y[0]; v[j + 1] = y[1];
+    for (int j = 0; j < 16; j += 4) {
+      f32x2 a = f32x2{v[j], v[j + 1]}, b = f32x2{v[j + 2], v[j + 3]};
+      gelu_pk4(a, b);
+      v[j] = a[0]; v[j + 1] = a[1]; v[j + 2] = b[0]; v[j + 3] = b[1];
     }
   } else if (EPI == EPI_RESID) {
     long rrow = m;
@@ -548,9 +575,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
         }
         if (EPI == EPI_GELU) {
 #pragma unroll
-          for (int j = 0; j < 16; j += 2) {
-            const f32x2 y = gelu_pk(f32x2{v[j], v[j + 1]});
-            v[j] = y[0]; v[j + 1] = y[1];
+          for (int j = 0; j < 16; j += 4) {
+            f32x2 a = f32x2{v[j], v[j + 1]}, b = f32x2{v[j + 2], v[j + 3]};
+            gelu_pk4(a, b);
+            v[j] = a[0]; v[j + 1] = a[1]; v[j + 2] = b[0]; v[j + 3] = b[1];
           }
         }
         if (scratch != nullptr) {

@@ -267,9 +267,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_stream(const GemmParams p) 
 #pragma unroll
         for (int j = 0; j < 16; ++j) y[j] = fmaf(acc[j >> 2][mi][j & 3], ws[j], bs[j]);
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          const f32x2 t = gelu_pk(f32x2{y[j], y[j + 1]});
-          y[j] = t[0] * inv[mi]; y[j + 1] = t[1] * inv[mi];
+        for (int j = 0; j < 16; j += 4) {
+          f32x2 ta = f32x2{y[j], y[j + 1]}, tb = f32x2{y[j + 2], y[j + 3]};
+          gelu_pk4(ta, tb);
+          y[j] = ta[0] * inv[mi]; y[j + 1] = ta[1] * inv[mi]; y[j + 2] = tb[0] * inv[mi]; y[j + 3] = tb[1] * inv[mi];
         }
         uint4 q;
         q.x = pack4_e4m3(y[0], y[1], y[2], y[3]);   q.y = pack4_e4m3(y[4], y[5], y[6], y[7]);
@@ -652,9 +653,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
         for (int j = 0; j < 16; ++j) y[j] = fmaf(acc[ni][mi][j] * xsr[mi], ws[j], bs[j]);
         if constexpr (EPI == EPI_GELU8) {
 #pragma unroll
-          for (int j = 0; j < 16; j += 2) {
-            const f32x2 t = gelu_pk(f32x2{y[j], y[j + 1]});
-            y[j] = t[0] * inv[mi]; y[j + 1] = t[1] * inv[mi];
+          for (int j = 0; j < 16; j += 4) {
+            f32x2 ta = f32x2{y[j], y[j + 1]}, tb = f32x2{y[j + 2], y[j + 3]};
+            gelu_pk4(ta, tb);
+            y[j] = ta[0] * inv[mi]; y[j + 1] = ta[1] * inv[mi]; y[j + 2] = tb[0] * inv[mi]; y[j + 3] = tb[1] * inv[mi];
           }
           uint4 q;
           q.x = pack4_e4m3(y[0], y[1], y[2], y[3]);   q.y = pack4_e4m3(y[4], y[5], y[6], y[7]);
