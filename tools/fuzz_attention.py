@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of rajni_attention (packed-token softmax attention with the keep_idx gather
-fused into its loads) against a torch fp32 reference, and of rajni_score_select's selection against the
+fused into its loads) against a torch fp32 reference, of rajni_attention_fp8 against the e4m3 rounding of those values, and of rajni_score_select's selection against the
 defined rule applied to the device's own scores.  python tools/fuzz_attention.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,6 +36,20 @@ def run(cases=100, seed=0, verbose=True):
         ref = ref.permute(0, 2, 1, 3).reshape(B, Np, H * D)
         err = float((out - ref).abs().max()); scale = float(ref.abs().max()) + 1e-6
         ok = err <= 2e-2 * scale and bool(torch.isfinite(out).all())
+        # e4m3 output rows (rajni_attention_fp8) where that kernel serves the launch: the stated rounding of the same values,
+        # one scale a random factor above their maximum, every row-scale slot filled with it
+        if D == 64 and Np <= 224:
+            osc = float(np.float32(scale * float(rng.choice([1.0, 3.0, 40.0])) / 448.0))
+            q8, rs = ops.attention_fp8(qkv, idx, H, scale_qk, osc)
+            deq = q8.view(torch.float8_e4m3fn).float() * osc
+            nat.lib().rajni_debug_force_attention(0)          # the persistent kernel's bf16 output: the same fp32 values, rounded to bf16
+            o0 = ops.attention(qkv, idx, H, scale_qk).float()
+            bound = torch.maximum(o0.abs() * 2.0 ** -4, torch.full_like(o0, osc * 2.0 ** -10)) * 1.001 + o0.abs() * 2.0 ** -8 + 1e-6 * scale
+            ok8 = bool(((deq - o0).abs() <= bound).all()) and bool((rs == osc).all())
+            if not ok8:
+                d = (deq - o0).abs() - bound
+                print(f"   fp8 out: worst excess {float(d.max()):.4g} at |o| {float(o0.flatten()[d.argmax()]):.4g}, osc {osc:.4g}, {int((d > 0).sum())} elements", flush=True)
+            ok = ok and ok8
         # selection on the same qkv: exactly the defined top-k of the device's scores, CLS first, ascending
         # score/select holds every token's V-bar (N x D fp32) or the logits (H x N) in LDS: stay inside 160 KiB
         lds_floats = H * D + max(H * N, N * D) + 2 * N + 2 * H + 512 + D + 24
