@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
 //   rounded fp32 division and the product one fp32 multiply, so a host restatement reproduces the bytes;
 //   hscale[r] (optional) = (1.0625 * ||o||_2 * wnorm + bmax) / 448: per-row scale of the MLP hidden activations
 //   from the Cauchy-Schwarz bound (the margin covers the <= 2^-4 relative change of ||o|| under quantisation).
-template <typename TX>
+// NC: 16-byte chunks per lane.  2 serves C <= 1024 - every ViT-B / ViT-L row - in 50 VGPRs instead of 70: 8 waves per SIMD instead of
+// 7, and no dead third / fourth chunk iterations: 31 -> 28 us per launch on ViT-B at batch 256 (the bf16-output kernel gains nothing
+// from the same change: it sits on the HBM rate; this one was short of waves to cover its four wave reductions per row)
+template <typename TX, int NC>
 __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict__ x, long xs,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             unsigned char* __restrict__ yq, float* __restrict__ yscale,
@@ -73,10 +76,10 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   if (row >= rows) return;
   const int nchunk = C >> 3;
   const TX* xr = x + (long)row * xs;
-  float v[LN_MAX_CHUNKS][8];
+  float v[NC][8];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
       load8<TX>(xr + c * 8, v[i]);
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   const float mean = wave_sum(sum) / (float)C;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
 #pragma unroll
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
   float amax = 0.f, osq = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
       float wv[8], bv[8];
@@ -120,9 +123,9 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
   const float inv = 1.0f / scale;
   unsigned char* yr = yq + (long)row * C;
-  int plo[LN_MAX_CHUNKS], phi[LN_MAX_CHUNKS];
+  int plo[NC], phi[NC];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NC; ++i) {
     plo[i] = phi[i] = 0;
     const int c = lane + i * 64;
     if (c < nchunk) {
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   // 16-byte stores: an even lane takes its odd neighbour's 8 bytes (adjacent chunks) - with 8-byte stores a wave
   // instruction wrote half sectors
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int c = lane + i * 64;
     const int nlo = __shfl_down(plo[i], 1, 64), nhi = __shfl_down(phi[i], 1, 64);
     if (c < nchunk && (lane & 1) == 0) {
@@ -200,11 +203,18 @@ int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b,
   RAJNI_REQUIRE(wnorm >= 0.f && bmax >= 0.f, RAJNI_ERR_INVALID, "rajni_layernorm_fp8: the hidden bound's constants must be >= 0");
   ProfScope prof(KC_LAYERNORM, s, 10.0 * rows * C, (x_f32 ? 5.0 : 3.0) * rows * C);
   const dim3 grid((rows + 3) / 4), block(256);
-  if (x_f32)
-    hipLaunchKernelGGL((layernorm_fp8_kernel<float>), grid, block, 0, s, (const float*)x, xs, w, b, (unsigned char*)yq,
+  const bool small = C <= 64 * 8 * 2;
+  if (x_f32 && small)
+    hipLaunchKernelGGL((layernorm_fp8_kernel<float, 2>), grid, block, 0, s, (const float*)x, xs, w, b, (unsigned char*)yq,
+                       yscale, hscale, wnorm, bmax, rows, C, eps);
+  else if (x_f32)
+    hipLaunchKernelGGL((layernorm_fp8_kernel<float, LN_MAX_CHUNKS>), grid, block, 0, s, (const float*)x, xs, w, b, (unsigned char*)yq,
+                       yscale, hscale, wnorm, bmax, rows, C, eps);
+  else if (small)
+    hipLaunchKernelGGL((layernorm_fp8_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (unsigned char*)yq,
                        yscale, hscale, wnorm, bmax, rows, C, eps);
   else
-    hipLaunchKernelGGL((layernorm_fp8_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (unsigned char*)yq,
+    hipLaunchKernelGGL((layernorm_fp8_kernel<bf16_t, LN_MAX_CHUNKS>), grid, block, 0, s, (const bf16_t*)x, xs, w, b, (unsigned char*)yq,
                        yscale, hscale, wnorm, bmax, rows, C, eps);
   RAJNI_CHECK_LAUNCH("layernorm_fp8_kernel");
   return RAJNI_OK;
