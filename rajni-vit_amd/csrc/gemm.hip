@@ -440,8 +440,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
     if (scratch != nullptr && pre.valid) {
       // ROWMAJOR epilogue of an interior tile (see prefetch_resid_rowmajor): per row group and column half, the wave's 16 x 32
       // accumulator block goes through its 2 KiB LDS scratch - written in the MFMA layout (lane = row l15, columns 4 g..),
-      // read back as 8 rows x 128 bytes per instruction (16-byte chunks XOR-swizzled by the row pair: conflict free both
-      // ways) - meets the residual rows loaded in that shape, and leaves as whole 128-byte lines.
+      // read back as 8 rows x 128 bytes per instruction (16-byte chunk c of row r in slot c ^ (r & 7): the eight contiguous
+      // lanes of a ds_write_b128 group hit eight slots, the sixteen lanes of a ds_read_b128 group sixteen of a 256-byte bank row) - meets the residual rows loaded in that shape, and leaves as whole 128-byte lines.
       int lane = g * 16 + l15;
       asm volatile("" : "+v"(lane));                              // (not hoisted out of the tile loop: see prefetch_resid_rowmajor)
       const int rr = lane >> 3, cc = lane & 7;                    // read-back: row rr (+ 8 j), 16-byte chunk cc of the half
@@ -469,14 +469,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
         for (int hc = 0; hc < 2; ++hc) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {   // n-tile 2 hc + q: chunk 4 q + g of row l15
-            const int slot = (4 * q + g) ^ ((l15 >> 1) & 3);
+            const int slot = (4 * q + g) ^ (l15 & 7);
             *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + slot * 16) = __builtin_bit_cast(bf16x8, acc[2 * hc + q][mi]);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int row = 8 * j + rr, slot = cc ^ ((row >> 1) & 3);
+            const int row = 8 * j + rr, slot = cc ^ (row & 7);
             const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
             const float4 r = pre.r[mi][2 * hc + j];
             float4 o;
@@ -523,14 +523,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
         for (int hc = 0; hc < 2; ++hc) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            const int slot = (4 * q + g) ^ ((l15 >> 1) & 3);
+            const int slot = (4 * q + g) ^ (l15 & 7);
             *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + slot * 16) = __builtin_bit_cast(bf16x8, acc[2 * hc + q][mi]);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int row = 8 * j + rr, slot = cc ^ ((row >> 1) & 3);
+            const int row = 8 * j + rr, slot = cc ^ (row & 7);
             const f32x4 a = __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + slot * 16));
             float4 o;
             o.x = fmaf(gam[hc][0], a[0] + bias[hc][0], r[2 * hc + j].x);
@@ -588,7 +588,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
           int lane = g * 16 + l15;
           asm volatile("" : "+v"(lane));
           const int rr = lane >> 3, cc = lane & 7;
-          const int key = (l15 >> 1) & 3;
+          const int key = l15 & 7;
           *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + ((g ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(v));
           *reinterpret_cast<bf16x8*>(scratch + l15 * 128 + (((4 + g) ^ key) << 4)) = __builtin_bit_cast(bf16x8, pack8(v + 8));
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -596,7 +596,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = 8 * j + rr;
-            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ ((row >> 1) & 3)) << 4)));
+            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ (row & 7)) << 4)));
             store_u4<RAJNI_FC1_NT && EPI == EPI_GELU>(Y + (long)(m_base + mi * 16 + row) * p.ldc + n0w + 8 * cc, q);
           }
           __builtin_amdgcn_wave_barrier();

@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
       if (inter) {
         // interior tile, bf16 output as whole 128-byte lines: per 32-row group the wave's 32 x 64 block (two 16-byte pieces
         // per lane and column tile: chunks 4 ni + 2 h, + 1 of row r) goes through 4 KiB of LDS behind the stages - slot =
-        // chunk ^ ((row >> 1) & 7), conflict free both ways - and leaves as 8 rows x 128 bytes per instruction.  Stored
+        // chunk ^ (row & 7), conflict free both ways - and leaves as 8 rows x 128 bytes per instruction.  Stored
         // straight from the accumulator layout an instruction touches 32 rows x 64 bytes (two lanes per row): half lines,
         // which a CU moves at a third of the rate (tools/pull_probe.hip) - the reason QKV used the 256 x 128 kernel.
         char* scratch = smem + LDS_BYTES + wave * 4096;
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
         bf16_t* Y = reinterpret_cast<bf16_t*>(p.Y) + n0w + 8 * cc;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-          const int key = (r >> 1) & 7;
+          const int key = r & 7;
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni) {
             float y[16];
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_tn_wide(const GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int row = 8 * j + rr;
-            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)));
+            const uint4 q = __builtin_bit_cast(uint4, *reinterpret_cast<const bf16x8*>(scratch + row * 128 + ((cc ^ (row & 7)) << 4)));
             *reinterpret_cast<uint4*>(Y + (long)(m_base + mi * 32 + row) * p.ldc) = q;
           }
           __builtin_amdgcn_wave_barrier();   // the group's reads are issued before the next group's writes
