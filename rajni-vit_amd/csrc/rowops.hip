@@ -4,6 +4,9 @@
 
 namespace {
 
+#ifndef RAJNI_LN_ROWS
+#define RAJNI_LN_ROWS 2   // rows per wave of the benchmark path's LayerNorm (1 = the one-row kernel; 3: 728, 4: 750 us per forward against 715)
+#endif
 constexpr int LN_MAX_CHUNKS = 4;  // 16-byte chunks per lane: C <= 64*8*4 = 2048
 
 template <typename TX, typename TY>
@@ -52,6 +55,74 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TX* __restrict__ x
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fmaf((v[i][j] - mean) * rstd, wv[j], bv[j]);
       store8<TY>(yr + c * 8, o);
+    }
+  }
+}
+
+// R rows per wave (fp32 rows in, bf16 out, C <= 1024): R times the loads in flight per wave.  The one-row kernel keeps 3 KB per wave in
+// flight at 8 waves per SIMD - Little's law put that short of the HBM rate: LayerNorm was a latency-bound kernel, not a bandwidth-bound one
+// (two rows, still 64 VGPRs = 8 waves: 772 -> 715 us per forward; the e4m3-output kernel, with four wave reductions per row, loses with two).
+template <int NC, int R>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, long xs, const float* __restrict__ w,
+                                                             const float* __restrict__ b, bf16_t* __restrict__ y, int rows, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + wave) * R;
+  if (r0 >= rows) return;
+  const int nchunk = C >> 3;
+  float v[R][NC][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float* xr = x + (long)(r0 + r < rows ? r0 + r : rows - 1) * xs;      // clamped: a short last group re-reads its last row
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) load8<float>(xr + c * 8, v[r][i]);
+    }
+  }
+  float mean[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[r][i][j];
+      }
+    }
+    mean[r] = wave_sum(sum) / (float)C;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[r][i][j] - mean[r];
+          ss += d * d;
+        }
+      }
+    }
+    rstd[r] = rsqrtf(wave_sum(ss) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float wv[8], bv[8];
+      load8<float>(w + c * 8, wv);
+      load8<float>(b + c * 8, bv);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf((v[r][i][j] - mean[r]) * rstd[r], wv[j], bv[j]);
+        if (r0 + r < rows) store8<bf16_t>(y + (long)(r0 + r) * C + c * 8, o);
+      }
     }
   }
 }
@@ -187,6 +258,9 @@ int launch_layernorm(const void* x, long xs, const float* w, const float* b, voi
   const dim3 grid((rows + 3) / 4), block(256);
   if (f32io)
     hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, xs, w, b, (float*)y, rows, C, eps);
+  else if (x_f32 && RAJNI_LN_ROWS > 1 && C <= 1024 && rows >= 4096)
+    hipLaunchKernelGGL((layernorm_rows_kernel<2, RAJNI_LN_ROWS>), dim3((rows + 4 * RAJNI_LN_ROWS - 1) / (4 * RAJNI_LN_ROWS)), block, 0, s,
+                       (const float*)x, xs, w, b, (bf16_t*)y, rows, C, eps);
   else if (x_f32)
     hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, xs, w, b, (bf16_t*)y, rows, C, eps);
   else

@@ -168,7 +168,8 @@ def test_linear_tile_order_blocks_do_not_change_results(nblk, tiling):
 # ---------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("x_f32", [False, True])
-@pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (33, 1024), (2, 128)])
+@pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (33, 1024), (2, 128),
+                                     (4097, 768), (5001, 1024), (4100, 384), (4096, 1280)])   # >= 4096 rows: the two-rows-per-wave kernel (C <= 1024)
 def test_layernorm(rows, Cc, x_f32):
     rng = np.random.default_rng(rows)
     x = rng.standard_normal((rows, Cc), dtype=np.float32) * 2 + 0.5
