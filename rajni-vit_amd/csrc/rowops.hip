@@ -4,6 +4,9 @@
 
 namespace {
 
+#ifndef RAJNI_LN8_ROWS
+#define RAJNI_LN8_ROWS 2  // ... of the e4m3-output LayerNorm
+#endif
 #ifndef RAJNI_LN_ROWS
 #define RAJNI_LN_ROWS 2   // rows per wave of the benchmark path's LayerNorm (1 = the one-row kernel; 3: 728, 4: 750 us per forward against 715)
 #endif
@@ -230,6 +233,120 @@ __global__ void __launch_bounds__(256) layernorm_fp8_kernel(const TX* __restrict
   }
 }
 
+// The e4m3-output LayerNorm with R rows per wave, stage by stage ACROSS the rows (their four wave reductions each overlap instead of
+// queueing up): fp32 rows, C <= 1024.  Same arithmetic per row as layernorm_fp8_kernel: the same bytes.
+template <int NC, int R>
+__global__ void __launch_bounds__(256) layernorm_fp8_rows_kernel(const float* __restrict__ x, long xs, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, unsigned char* __restrict__ yq,
+                                                                 float* __restrict__ yscale, float* __restrict__ hscale, float wnorm,
+                                                                 float bmax, int rows, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + wave) * R;
+  if (r0 >= rows) return;
+  const int nchunk = C >> 3;
+  float v[R][NC][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float* xr = x + (long)(r0 + r < rows ? r0 + r : rows - 1) * xs;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) load8<float>(xr + c * 8, v[r][i]);
+    }
+  }
+  float mean[R], rstd[R], amax[R], osq[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[r][i][j];
+      }
+    }
+    mean[r] = sum;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(mean[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[r][i][j] - mean[r];
+          ss += d * d;
+        }
+      }
+    }
+    rstd[r] = ss;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum(rstd[r]) / (float)C + eps);
+#pragma unroll
+  for (int r = 0; r < R; ++r) { amax[r] = 0.f; osq[r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float wv[8], bv[8];
+      load8<float>(w + c * 8, wv);
+      load8<float>(b + c * 8, bv);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float o = fmaf((v[r][i][j] - mean[r]) * rstd[r], wv[j], bv[j]);
+          v[r][i][j] = o;
+          amax[r] = fmaxf(amax[r], fabsf(o));
+          osq[r] = fmaf(o, o, osq[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) { amax[r] = wave_max(amax[r]); osq[r] = wave_sum(osq[r]); }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + r;
+    const bool live = row < rows;
+    const float scale = amax[r] > 0.f ? amax[r] / 448.0f : 1.0f;
+    const float inv = 1.0f / scale;
+    unsigned char* yr = yq + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int lo = 0, hi = 0;
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = __builtin_amdgcn_fmed3f(v[r][i][j] * inv, -448.f, 448.f);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+      }
+      const int nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
+      if (live && c < nchunk && (lane & 1) == 0) {
+        if (c + 1 < nchunk) *reinterpret_cast<uint4*>(yr + c * 8) = make_uint4((unsigned)lo, (unsigned)hi, (unsigned)nlo, (unsigned)nhi);
+        else *reinterpret_cast<uint2*>(yr + c * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+      }
+    }
+    if (live && lane == 0) {
+      yscale[row] = scale;
+      if (hscale != nullptr) {
+        const float bound = fmaf(1.0625f * sqrtf(osq[r]), wnorm, bmax);
+        hscale[row] = bound > 0.f ? bound / 448.0f : 1.0f;
+      }
+    }
+  }
+}
+
 // dst[b, j, :] = src[b, idx[b, j], :]   rows of `row_chunks` 16-byte chunks; one wave per row
 __global__ void __launch_bounds__(256) gather_rows_kernel(const uint4* __restrict__ src,
                                                          const int* __restrict__ idx,
@@ -278,7 +395,10 @@ int launch_layernorm_fp8(const void* x, long xs, const float* w, const float* b,
   ProfScope prof(KC_LAYERNORM, s, 10.0 * rows * C, (x_f32 ? 5.0 : 3.0) * rows * C);
   const dim3 grid((rows + 3) / 4), block(256);
   const bool small = C <= 64 * 8 * 2;
-  if (x_f32 && small)
+  if (x_f32 && small && RAJNI_LN8_ROWS > 1 && rows >= 4096)
+    hipLaunchKernelGGL((layernorm_fp8_rows_kernel<2, RAJNI_LN8_ROWS>), dim3((rows + 4 * RAJNI_LN8_ROWS - 1) / (4 * RAJNI_LN8_ROWS)), block, 0, s,
+                       (const float*)x, xs, w, b, (unsigned char*)yq, yscale, hscale, wnorm, bmax, rows, C, eps);
+  else if (x_f32 && small)
     hipLaunchKernelGGL((layernorm_fp8_kernel<float, 2>), grid, block, 0, s, (const float*)x, xs, w, b, (unsigned char*)yq,
                        yscale, hscale, wnorm, bmax, rows, C, eps);
   else if (x_f32)

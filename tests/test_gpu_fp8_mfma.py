@@ -33,7 +33,8 @@ def random_e4m3(rng, shape):
 
 
 @pytest.mark.parametrize("rows,Cc,x_f32", [(300, 768, True), (64, 512, False), (1000, 1024, True), (5, 256, True),
-                                           (37, 1280, True), (9, 2048, False)])       # > 1024: the four-chunk instantiation
+                                           (37, 1280, True), (9, 2048, False),       # > 1024: the four-chunk instantiation
+                                           (4099, 768, True), (4096, 1024, True)])   # >= 4096 fp32 rows: two rows per wave
 def test_layernorm_fp8_rule(rows, Cc, x_f32):
     rng = np.random.default_rng(rows + Cc)
     x = rng.standard_normal((rows, Cc), dtype=np.float32) * rng.uniform(0.05, 30.0, size=(rows, 1)).astype(np.float32)
